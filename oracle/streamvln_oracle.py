@@ -1,0 +1,355 @@
+"""CPU oracle: a plain fp32 restatement of StreamVLN's streaming-inference path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under `streamvln_amd/` imports this file; only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may.  The shipped
+path is the HIP engine behind `include/streamvln_hip.h` and fails loudly without it.
+
+What it restates (reference file:line under /root/reference unless noted):
+  preprocess            llava/model/multimodal_encoder/siglip_encoder.py:47-67
+  SigLIP embeddings     siglip_encoder.py:169-174
+  SigLIP encoder layer  siglip_encoder.py:197-305 (eager attention, fp32 softmax)
+  vision tower output   siglip_encoder.py:563-589 (hidden_states[-1], no post_layernorm)
+  mm_projector          llava/model/multimodal_projector/builder.py:41-48 (Linear-GELU(erf)-Linear)
+  get_2dPool            streamvln/model/stream_video_vln.py:53-73 (bilinear, align_corners=False)
+  encode_rgbd           stream_video_vln.py:102-142
+  token splice          stream_video_vln.py:144-291 (batch of one env)
+  turn protocol         stream_video_vln.py:353-479 + transformers 4.45.1 GenerationMixin
+                        (greedy; cache_position = arange(L_total)[P:])
+  Qwen2 decoder         transformers Qwen2 equations (third-party, pinned 4.45.1 in the
+                        reference's requirements.txt:140; same math as the container copy
+                        transformers/models/qwen2/modeling_qwen2.py:35-48,91-135,150-173,238-252,269-299)
+
+Parity pin: `oracle/make_golden.py` imports the reference's own modules in the build
+container, loads the same synthetic weights into them and asserts this file reproduces
+their outputs (vision tower, projector+pool, splice, multi-turn greedy decode) before it
+writes `tests/golden/*.npz`.  The reference has no tests or fixtures of its own
+(SURVEY.md F8), so those generated vectors are the pin.
+
+All arithmetic is fp32 on the CPU via torch tensor ops (matmul / exp / erf / tanh); no
+nn.Module of transformers or of the reference is used here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+IMAGE_TOKEN_INDEX = -200    # streamvln/utils/utils.py:9
+MEMORY_TOKEN_INDEX = -300   # streamvln/utils/utils.py:15
+VT = "model.vision_tower.vision_tower.vision_model."
+
+W = Dict[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------- preprocess
+def siglip_preprocess(rgb: np.ndarray, size: int = 384) -> np.ndarray:
+    """uint8 [H,W,3] -> fp32 [3,size,size] in [-1,1].  siglip_encoder.py:47-67:
+    PIL bicubic resize to (size,size) (aspect not preserved), *1/255 (in fp64, cast fp32),
+    (x-0.5)/0.5, channels first."""
+    from PIL import Image
+    img = Image.fromarray(np.asarray(rgb, dtype=np.uint8)).convert("RGB")
+    img = img.resize((size, size), resample=Image.BICUBIC)
+    a = np.asarray(img).astype(np.float64) * (1.0 / 255.0)
+    a = a.astype(np.float32)
+    a = (a - np.float32(0.5)) / np.float32(0.5)
+    return np.ascontiguousarray(a.transpose(2, 0, 1))
+
+
+# ----------------------------------------------------------------------------- small math
+def layer_norm(x, g, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * g + b
+
+
+def gelu_tanh(x):           # ACT2FN["gelu_pytorch_tanh"], siglip_encoder.py:83,247
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def gelu_erf(x):            # nn.GELU() default, multimodal_projector/builder.py:45
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def silu(x):
+    return x / (1.0 + torch.exp(-x))
+
+
+def rms_norm(x, g, eps):    # Qwen2RMSNorm (modeling_qwen2.py:238-252)
+    var = (x * x).mean(-1, keepdim=True)
+    return g * (x * torch.rsqrt(var + eps))
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+# ----------------------------------------------------------------------------- vision
+def siglip_embeddings(w: W, cfg, pixels: torch.Tensor) -> torch.Tensor:
+    """[F,3,S,S] -> [F,729,Hv]: valid 14x14/14 conv + bias, flatten, + pos-emb (siglip_encoder.py:169-174).
+    384 = 27*14 + 6: the last 6 rows/cols are dropped by the valid conv."""
+    F_, C, _, _ = pixels.shape
+    p, side = cfg.v_patch, cfg.v_side
+    x = pixels[:, :, : side * p, : side * p]
+    x = x.reshape(F_, C, side, p, side, p).permute(0, 2, 4, 1, 3, 5).reshape(F_, side * side, C * p * p)
+    wk = w[VT + "embeddings.patch_embedding.weight"].reshape(cfg.v_hidden, -1)
+    y = x @ wk.t() + w[VT + "embeddings.patch_embedding.bias"]
+    return y + w[VT + "embeddings.position_embedding.weight"][None]
+
+
+def siglip_attention(w: W, cfg, L: str, x: torch.Tensor) -> torch.Tensor:
+    """siglip_encoder.py:197-239: 16 heads x hd 72, scale hd^-0.5, softmax in fp32, all biases."""
+    F_, S, Hv = x.shape
+    nh, hd = cfg.v_heads, cfg.v_head_dim
+    q = linear(x, w[L + "self_attn.q_proj.weight"], w[L + "self_attn.q_proj.bias"])
+    k = linear(x, w[L + "self_attn.k_proj.weight"], w[L + "self_attn.k_proj.bias"])
+    v = linear(x, w[L + "self_attn.v_proj.weight"], w[L + "self_attn.v_proj.bias"])
+    q = q.view(F_, S, nh, hd).transpose(1, 2)
+    k = k.view(F_, S, nh, hd).transpose(1, 2)
+    v = v.view(F_, S, nh, hd).transpose(1, 2)
+    s = (q @ k.transpose(2, 3)) * (hd ** -0.5)
+    s = s - s.amax(-1, keepdim=True)
+    p = torch.exp(s)
+    p = p / p.sum(-1, keepdim=True)
+    o = (p @ v).transpose(1, 2).reshape(F_, S, Hv)
+    return linear(o, w[L + "self_attn.out_proj.weight"], w[L + "self_attn.out_proj.bias"])
+
+
+def siglip_layer(w: W, cfg, i: int, x: torch.Tensor) -> torch.Tensor:
+    """siglip_encoder.py:269-305 (pre-LN residual block)."""
+    L = f"{VT}encoder.layers.{i}."
+    h = layer_norm(x, w[L + "layer_norm1.weight"], w[L + "layer_norm1.bias"], cfg.v_eps)
+    x = x + siglip_attention(w, cfg, L, h)
+    h = layer_norm(x, w[L + "layer_norm2.weight"], w[L + "layer_norm2.bias"], cfg.v_eps)
+    h = linear(h, w[L + "mlp.fc1.weight"], w[L + "mlp.fc1.bias"])
+    h = gelu_tanh(h)
+    h = linear(h, w[L + "mlp.fc2.weight"], w[L + "mlp.fc2.bias"])
+    return x + h
+
+
+def vision_tower(w: W, cfg, pixels: torch.Tensor) -> torch.Tensor:
+    """SigLipVisionTower.forward (siglip_encoder.py:576-589): hidden_states[-1] of the
+    26-layer encoder = output of the last run layer, before post_layernorm; head = Identity."""
+    x = siglip_embeddings(w, cfg, pixels)
+    for i in range(cfg.v_layers):
+        x = siglip_layer(w, cfg, i, x)
+    assert x.shape[-2] == cfg.v_tokens
+    return x
+
+
+def mm_projector(w: W, x: torch.Tensor) -> torch.Tensor:
+    """mlp2x_gelu (multimodal_projector/builder.py:41-48)."""
+    h = linear(x, w["model.mm_projector.0.weight"], w["model.mm_projector.0.bias"])
+    h = gelu_erf(h)
+    return linear(h, w["model.mm_projector.2.weight"], w["model.mm_projector.2.bias"])
+
+
+def bilinear_taps(n_in: int, n_out: int):
+    """Source indices/weights of F.interpolate(mode='bilinear', align_corners=False):
+    src = max((dst + 0.5) * n_in/n_out - 0.5, 0); i0 = floor(src); i1 = min(i0+1, n_in-1)."""
+    scale = n_in / n_out
+    taps = []
+    for d in range(n_out):
+        src = max((d + 0.5) * scale - 0.5, 0.0)
+        i0 = min(int(math.floor(src)), n_in - 1)
+        i1 = min(i0 + 1, n_in - 1)
+        l1 = np.float32(src - i0)
+        taps.append((i0, i1, np.float32(1.0) - l1, l1))
+    return taps
+
+
+def pool_bilinear(cfg, feat: torch.Tensor) -> torch.Tensor:
+    """get_2dPool, mode 'bilinear' (stream_video_vln.py:53-73): [F,729,C] -> [F,196,C]."""
+    F_, _, C = feat.shape
+    side, out = cfg.v_side, cfg.pool_side
+    x = feat.view(F_, side, side, C)
+    taps = bilinear_taps(side, out)
+    rows = []
+    for (y0, y1, wy0, wy1) in taps:
+        cols = []
+        for (x0, x1, wx0, wx1) in taps:
+            # ATen upsample_bilinear2d: w0y*(w0x*a + w1x*b) + w1y*(w0x*c + w1x*d)
+            top = float(wx0) * x[:, y0, x0] + float(wx1) * x[:, y0, x1]
+            bot = float(wx0) * x[:, y1, x0] + float(wx1) * x[:, y1, x1]
+            cols.append(float(wy0) * top + float(wy1) * bot)
+        rows.append(torch.stack(cols, 1))
+    return torch.stack(rows, 1).reshape(F_, out * out, C)
+
+
+def encode_rgbd(w: W, cfg, images: torch.Tensor, time_ids, num_history: Optional[int]):
+    """stream_video_vln.py:102-142 for a batch of one env.
+    images [1,V,3,S,S] -> (image_feats [V',196,H], memory_feats [N*196,H] or None).
+    depths/poses/intrinsics/task_ids are accepted by the reference but never read."""
+    assert images.shape[0] == 1
+    V = images.shape[1]
+    feats = vision_tower(w, cfg, images[0])                      # [V,729,Hv]
+    memory = None
+    if V != 1:
+        start_idx = time_ids[0][0] if time_ids[0] is not None else 0
+        if start_idx != 0:
+            nh = num_history
+            his = pool_bilinear(cfg, mm_projector(w, feats[:nh]))  # [N,196,H]
+            memory = his.flatten(0, 1)
+            feats = feats[nh:]
+    img = pool_bilinear(cfg, mm_projector(w, feats))
+    return img, memory
+
+
+def splice_embeds(w: W, input_ids: Sequence[int], image_feats, memory_feats) -> torch.Tensor:
+    """prepare_inputs_labels_for_multimodal (stream_video_vln.py:182-238), one sample:
+    text spans are embedded, each -200 is replaced by the next frame's 196 rows and each
+    -300 by the memory block, in order of appearance."""
+    emb = w["model.embed_tokens.weight"]
+    out, img_id, mem_id = [], 0, 0
+    for t in input_ids:
+        t = int(t)
+        if t == IMAGE_TOKEN_INDEX:
+            out.append(image_feats[img_id]); img_id += 1
+        elif t == MEMORY_TOKEN_INDEX:
+            assert mem_id == 0 and memory_feats is not None
+            out.append(memory_feats); mem_id += 1
+        else:
+            out.append(emb[t][None])
+    return torch.cat(out, 0)
+
+
+# ----------------------------------------------------------------------------- Qwen2
+def rope_cos_sin(positions: torch.Tensor, hd: int, theta: float):
+    """Qwen2RotaryEmbedding (modeling_qwen2.py:91-117): inv_freq = theta^(-2i/hd), fp32."""
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = positions.to(torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat((fr, fr), -1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), -1)
+
+
+class KVCache:
+    """Contiguous per-layer K/V (what DynamicCache holds)."""
+
+    def __init__(self, layers: int):
+        self.k: List[Optional[torch.Tensor]] = [None] * layers
+        self.v: List[Optional[torch.Tensor]] = [None] * layers
+
+    def __len__(self):
+        return 0 if self.k[0] is None else self.k[0].shape[1]
+
+    def update(self, i, k, v):
+        self.k[i] = k if self.k[i] is None else torch.cat((self.k[i], k), 1)
+        self.v[i] = v if self.v[i] is None else torch.cat((self.v[i], v), 1)
+        return self.k[i], self.v[i]
+
+
+def qwen2_layer(w: W, cfg, i: int, x: torch.Tensor, pos: torch.Tensor, cache: KVCache) -> torch.Tensor:
+    """One decoder layer on T new positions (modeling_qwen2.py:195-235,269-299).
+    x [T,H]; pos [T] absolute positions; causal over cache + new (bottom-right aligned)."""
+    L = f"model.layers.{i}."
+    T = x.shape[0]
+    nq, nkv, hd = cfg.q_heads, cfg.kv_heads, cfg.head_dim
+    h = rms_norm(x, w[L + "input_layernorm.weight"], cfg.rms_eps)
+    q = linear(h, w[L + "self_attn.q_proj.weight"], w[L + "self_attn.q_proj.bias"]).view(T, nq, hd)
+    k = linear(h, w[L + "self_attn.k_proj.weight"], w[L + "self_attn.k_proj.bias"]).view(T, nkv, hd)
+    v = linear(h, w[L + "self_attn.v_proj.weight"], w[L + "self_attn.v_proj.bias"]).view(T, nkv, hd)
+    cos, sin = rope_cos_sin(pos, hd, cfg.rope_theta)
+    q = q * cos[:, None] + rotate_half(q) * sin[:, None]
+    k = k * cos[:, None] + rotate_half(k) * sin[:, None]
+    kc, vc = cache.update(i, k.transpose(0, 1), v.transpose(0, 1))     # [nkv, len, hd]
+    S = kc.shape[1]
+    g = nq // nkv
+    qh = q.transpose(0, 1).reshape(nkv, g, T, hd)
+    s = torch.einsum("kgtd,ksd->kgts", qh, kc) * (hd ** -0.5)
+    key_pos = torch.arange(S)[None, :]
+    mask = key_pos > pos[:, None]                                       # key visible iff key_pos <= query pos
+    s = s.masked_fill(mask[None, None], float("-inf"))
+    s = s - s.amax(-1, keepdim=True)
+    p = torch.exp(s)
+    p = p / p.sum(-1, keepdim=True)
+    o = torch.einsum("kgts,ksd->kgtd", p, vc).reshape(nq, T, hd).transpose(0, 1).reshape(T, nq * hd)
+    x = x + linear(o, w[L + "self_attn.o_proj.weight"])
+    h = rms_norm(x, w[L + "post_attention_layernorm.weight"], cfg.rms_eps)
+    gate = linear(h, w[L + "mlp.gate_proj.weight"])
+    up = linear(h, w[L + "mlp.up_proj.weight"])
+    return x + linear(silu(gate) * up, w[L + "mlp.down_proj.weight"])
+
+
+def qwen2_forward(w: W, cfg, x: torch.Tensor, start: int, cache: KVCache):
+    """Run T new positions [start, start+T) through all layers; returns final-norm hidden [T,H]."""
+    assert len(cache) == start
+    pos = torch.arange(start, start + x.shape[0])
+    for i in range(cfg.layers):
+        x = qwen2_layer(w, cfg, i, x, pos, cache)
+    return rms_norm(x, w["model.norm.weight"], cfg.rms_eps)
+
+
+def lm_logits(w: W, h_last: torch.Tensor) -> torch.Tensor:
+    return h_last @ w["lm_head.weight"].t()
+
+
+def greedy_pick(logits: torch.Tensor):
+    """argmax with lowest-index tie break (torch.argmax on CPU) + top-2 margin."""
+    top2 = torch.topk(logits, 2)
+    tok = int(torch.argmax(logits))
+    return tok, float(top2.values[0] - top2.values[1])
+
+
+# ----------------------------------------------------------------------------- session
+class GenerateOutput:
+    def __init__(self, sequences, past_key_values, hidden, margins):
+        self.sequences = sequences            # int64 [1, n_new]  (new tokens only, EOS included)
+        self.past_key_values = past_key_values
+        self.hidden = hidden                  # fp32 [n_new, H]: final-norm hidden that produced each token
+        self.margins = margins                # top-2 logit margin per generated token
+
+
+class OracleStreamVLN:
+    """Same call surface as the reference's StreamVLNForCausalLM for the streaming path
+    (reset / reset_for_env / generate), computing everything in fp32 on the CPU."""
+
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], num_history: Optional[int] = None):
+        self.cfg = cfg
+        self.w = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in weights.items()}
+        self.num_history = num_history
+        self.reset(1)
+
+    def reset(self, env_num: int):                       # stream_video_vln.py:473-475
+        self.curr_t = [0] * env_num
+        self.cache = [dict() for _ in range(env_num)]    # (reference aliases one dict; per-env here)
+
+    def reset_for_env(self, env_idx: int):               # stream_video_vln.py:477-479
+        self.curr_t[env_idx] = 0
+        self.cache[env_idx] = dict()
+
+    @torch.no_grad()
+    def generate(self, inputs, images, env_id=0, time_ids=None, past_key_values: Optional[KVCache] = None,
+                 max_new_tokens: int = 10000, eos_token_ids: Sequence[int] = (), **_ignored) -> GenerateOutput:
+        cfg, w = self.cfg, self.w
+        ids = [int(t) for t in np.asarray(inputs).reshape(-1)]
+        if len(ids) == 1:
+            raise NotImplementedError("single-token `inputs` bypasses the multimodal path in the reference")
+        images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        img, mem = encode_rgbd(w, cfg, images, time_ids, self.num_history)
+        new = splice_embeds(w, ids, img, mem)
+        st = self.cache[env_id]
+        st["inputs_embeds"] = new if self.curr_t[env_id] == 0 else torch.cat((st["inputs_embeds"], new), 0)
+        self.curr_t[env_id] += 1
+        E = st["inputs_embeds"]
+        cache = past_key_values if past_key_values is not None else KVCache(cfg.layers)
+        P, L_total = len(cache), E.shape[0]
+        assert L_total > P
+        eos = set(int(e) for e in eos_token_ids)
+        h = qwen2_forward(w, cfg, E[P:], P, cache)[-1]
+        out, hid, margins = [], [], []
+        while True:
+            tok, margin = greedy_pick(lm_logits(w, h))
+            out.append(tok); hid.append(h.clone()); margins.append(margin)
+            if tok in eos or len(out) >= max_new_tokens:
+                break
+            x = w["model.embed_tokens.weight"][tok][None]
+            h = qwen2_forward(w, cfg, x, len(cache), cache)[-1]
+        assert len(cache) == L_total + len(out) - 1
+        return GenerateOutput(torch.tensor([out], dtype=torch.long), cache, torch.stack(hid), margins)

@@ -1,0 +1,143 @@
+"""Host-side streaming agent: the caller of the hot path.
+
+Mirrors the reference's `VLNEvaluator.step` (streamvln/streamvln_agent.py:169-258) and the
+identical turn logic inlined in the Habitat loop (streamvln/streamvln_eval.py:290-350):
+
+  * every env step records the preprocessed frame and its time id;
+  * a model turn happens when the pending action queue is empty: first turn of a window
+    builds the system+instruction prompt (with `<memory>` iff step_id != 0), later turns a
+    short "<conjunction> <image>." prompt; `inputs = cat(prev output_ids, new ids)`;
+  * at `step_id % num_frames == 0` (step_id != 0) the history frames
+    `rgb_list[0 : t0 : t0 // num_history]` are prepended (streamvln_eval.py:313-321);
+  * after the step that makes `step_id % num_frames == 0` the window is reset:
+    `model.reset_for_env`, `output_ids = None`, `past_key_values = None`, `time_ids = []`
+    (streamvln_eval.py:346-350).
+
+The model is anything exposing the reference's operator surface
+(`generate(...)`, `reset_for_env(i)`, `get_vision_tower().image_processor`): the HIP-backed
+`streamvln_amd.StreamVLNForCausalLM`, or the CPU oracle in tests.
+"""
+from __future__ import annotations
+
+import itertools
+import re
+from collections import OrderedDict
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+ACTIONS2IDX = OrderedDict({"STOP": [0], "↑": [1], "←": [2], "→": [3]})   # streamvln_agent.py:52-57
+
+CONJUNCTIONS = [                                                        # streamvln_agent.py:60-68
+    "you can see ", "in front of you is ", "there is ", "you can spot ",
+    "you are toward the ", "ahead of you is ", "in your sight is ",
+]
+
+
+def parse_actions(output: str) -> List[int]:
+    """streamvln_agent.py:101-107 / streamvln_eval.py:382-389."""
+    pattern = "|".join(re.escape(a) for a in ACTIONS2IDX)
+    matches = re.compile(pattern).findall(output)
+    return list(itertools.chain.from_iterable(ACTIONS2IDX[m] for m in matches))
+
+
+class StreamingAgent:
+    """Stateful single-env agent.  `prompt_encoder(first_turn, with_memory, instruction)`
+    returns the new turn's token ids (with -200/-300 sentinels); `decode_actions(ids)` turns the
+    generated ids into an action list (tokenizer.batch_decode + parse_actions in the reference)."""
+
+    def __init__(self, model, prompt_encoder: Callable, num_frames: int = 32, num_future_steps: int = 4,
+                 num_history: Optional[int] = 8, env_id: int = 0, device: str = "cpu",
+                 image_dtype: torch.dtype = torch.float32, max_new_tokens: int = 10000,
+                 eos_token_ids: Sequence[int] = (), decode_actions: Optional[Callable] = None,
+                 preprocess: Optional[Callable] = None):
+        self.model = model
+        self.prompt_encoder = prompt_encoder
+        self.num_frames, self.num_future_steps, self.num_history = num_frames, num_future_steps, num_history
+        self.env_id, self.device, self.image_dtype = env_id, device, image_dtype
+        self.max_new_tokens, self.eos_token_ids = max_new_tokens, tuple(eos_token_ids)
+        self.decode_actions = decode_actions or (lambda ids: [1] * num_future_steps)
+        if preprocess is None:
+            proc = model.get_vision_tower().image_processor
+            preprocess = lambda rgb: proc.preprocess_array(rgb)
+        self.preprocess = preprocess
+        self.turn_log: List[dict] = []
+        self.reset_memory()
+
+    def reset_memory(self):                                   # streamvln_agent.py:87-99
+        self.rgb_list: List[torch.Tensor] = []
+        self.time_ids: List[int] = []
+        self.action_seq: List[int] = []
+        self.output_ids = None
+        self.past_key_values = None
+        self.step_id = 0
+        self.last_image = None
+        self.model.reset_for_env(self.env_id)
+
+    # -- one model turn ---------------------------------------------------------------
+    def _turn(self, instruction: str):
+        first = self.output_ids is None
+        with_memory = first and self.step_id != 0
+        ids = torch.tensor([self.prompt_encoder(first, with_memory, instruction)], dtype=torch.long)
+        if not first:
+            ids = torch.cat([self.output_ids.to(ids.device), ids], dim=1)
+        images = self.rgb_list[-1:]
+        if self.step_id != 0 and self.step_id % self.num_frames == 0:
+            t0 = self.time_ids[0]
+            if self.num_history is None:
+                hist = slice(0, t0, self.num_future_steps)
+            else:
+                hist = slice(0, t0, t0 // self.num_history)
+            images = self.rgb_list[hist] + images
+        V = len(images)
+        batch = {
+            "images": torch.stack(images).unsqueeze(0).to(self.device).to(self.image_dtype),
+            # depths / poses / intrinsics are built by the reference callers and ignored by the model
+            "depths": torch.zeros(1, V, 1, 1), "poses": torch.zeros(1, V, 4, 4), "intrinsics": torch.zeros(1, V, 4, 4),
+            "inputs": ids.to(self.device), "env_id": self.env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
+        }
+        out = self.model.generate(**batch, do_sample=False, num_beams=1, max_new_tokens=self.max_new_tokens,
+                                  use_cache=True, return_dict_in_generate=True,
+                                  past_key_values=self.past_key_values, eos_token_ids=self.eos_token_ids)
+        self.output_ids = out.sequences
+        self.past_key_values = out.past_key_values
+        self.turn_log.append({"step_id": self.step_id, "n_inputs": int(ids.shape[1]), "views": V,
+                              "memory": bool(with_memory), "out": out})
+        actions = list(self.decode_actions(out.sequences))
+        return actions if len(actions) else [0]               # streamvln_eval.py:340-341
+
+    # -- eval-loop flavour: one env step, returns the action taken -------------------
+    def act(self, rgb: np.ndarray, instruction: str = "") -> int:
+        """One environment step of the Habitat loop (streamvln_eval.py:247-350)."""
+        self.time_ids.append(self.step_id)
+        self.rgb_list.append(self.preprocess(rgb))
+        if len(self.action_seq) == 0:
+            self.action_seq = self._turn(instruction)
+        action = self.action_seq.pop(0)
+        self.step_id += 1
+        if self.step_id % self.num_frames == 0:
+            self.model.reset_for_env(self.env_id)
+            self.output_ids = None
+            self.past_key_values = None
+            self.time_ids = []
+        return action
+
+    # -- real-world flavour ------------------------------------------------------------
+    def step(self, idx: int, rgb: np.ndarray, instruction_text: str = "", run_model: bool = False):
+        """`VLNEvaluator.step` (streamvln_agent.py:169-258).  The caller increments
+        `self.step_id` (http_realworld_server.py:112)."""
+        if run_model:
+            self.last_image = self.preprocess(rgb)
+        image = self.last_image
+        self.time_ids.append(self.step_id)
+        self.rgb_list.append(image)
+        if not run_model:
+            if (self.step_id + 1) % self.num_frames == 0:
+                self.model.reset_for_env(idx)
+                self.output_ids = None
+                self.past_key_values = None
+                self.time_ids = []
+            return None, 0, None
+        actions = self._turn(instruction_text)
+        return actions, 0.0, self.turn_log[-1]["out"]
