@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- action-steps/s of the StreamVLN streaming-inference hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): StreamVLN-Qwen-1.5 = SigLIP-so400m + Qwen2-7B at true
+size, bf16, seeded random-init weights, synthetic 640x480 RGB stream, 8-frame window
+(num_frames 32 / num_future_steps 4 / num_history 8), one env per GPU.  A "step" = one model turn
+(new frame in -> 4 action tokens + EOS out = 4 environment actions): vision encode of the new frame
+(9 frames at a window restart), splice, LLM prefill of the turn's tokens over the retained KV window, 5 greedy
+decode steps.  Turns cycle through 64-env-step episodes: turn 0 = episode start (T=376), turns 1-7 steady
+(T=212), turn 8 = window restart with the 8-frame <memory> block (T=1952, 9 ViT frames), turns 9-15 steady.
+Frames are preprocessed and resident in HBM before the timed region; `value` = 4 * turns / time over all ranks.
+
+Extra objects on the JSON line:
+  roofline      the gate/up SwiGLU GEMV of the decode step (largest single weight stream: 2*I*H*2 B = 271.6 MB per
+                launch, HBM-bound); `achieved` = those bytes / its mean duration, measured live with HIP events
+                on the engine's stream around the layer-0 launch of every decode step in the timed region.
+  cpu_baseline  the CPU oracle (fp32 port of the reference path, torch CPU, all host threads) on a bounded sample of
+                the same steady turn (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--config", default="streamvln_qwen2_7b")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+NUM_FRAMES, NUM_FUTURE, NUM_HISTORY, EP_STEPS, DECODE_TOKENS = 32, 4, 8, 64, 5
+
+
+class Runner:
+    """Drives the agent turn by turn on frames that are already resident on the GPU."""
+
+    def __init__(self, model, cfg, rank):
+        from streamvln_amd.agent import StreamingAgent
+        from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+        proc = model.get_vision_tower().image_processor
+        self.frames = [proc.preprocess_array(synthetic_frame(rank, s)).cuda() for s in range(EP_STEPS)]
+        torch.cuda.synchronize()
+        self.agent = StreamingAgent(model, SyntheticPromptEncoder(cfg), num_frames=NUM_FRAMES, num_future_steps=NUM_FUTURE,
+                                    num_history=NUM_HISTORY, device="cuda", max_new_tokens=DECODE_TOKENS, eos_token_ids=(),
+                                    preprocess=lambda idx: self.frames[idx])
+        self.step = 0
+        self.actions = 0
+
+    def turn(self):
+        """run env steps until one model turn has happened"""
+        n0 = len(self.agent.turn_log)
+        while len(self.agent.turn_log) == n0:
+            if self.step == EP_STEPS:                       # next episode
+                self.agent.reset_memory()
+                self.step = 0
+            self.agent.act(self.step)
+            self.step += 1
+            self.actions += 1
+        self.agent.turn_log[:] = self.agent.turn_log[-1:]
+
+
+def cpu_baseline(cfg_true):
+    """Oracle (fp32 CPU port of the reference path) on a bounded sample of one steady turn:
+    1 ViT layer (1 frame) x26, projector + pool, 1 LLM layer prefill T=212 over C=1676 and 5 decode steps x28,
+    lm_head x6.  Weight VALUES are irrelevant to the timing, so they are torch.rand here (no 30 GB synthesis)."""
+    from dataclasses import replace
+    from oracle import streamvln_oracle as O
+    cfg = replace(cfg_true, v_layers=1, layers=1)
+    torch.manual_seed(0)
+    from streamvln_amd.weights import tensor_specs
+    w = {s.name: (torch.rand(s.shape) * 2 - 1) * s.half_width + s.base for s in tensor_specs(cfg)}
+    threads = torch.get_num_threads()
+    T, C, H = 212, 1676, cfg.hidden
+
+    def timed(fn, reps=2):
+        best = 1e9
+        for _ in range(reps):
+            t = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t)
+        return best
+    pix = torch.rand(1, 3, cfg.v_image, cfg.v_image) * 2 - 1
+    x0 = O.siglip_embeddings(w, cfg, pix)
+    t_vit_layer = timed(lambda: O.siglip_layer(w, cfg, 0, x0))
+    t_embed = timed(lambda: O.siglip_embeddings(w, cfg, pix))
+    t_proj = timed(lambda: O.pool_bilinear(cfg, O.mm_projector(w, x0)), reps=1)
+    cache = O.KVCache(1)
+    O.qwen2_layer(w, cfg, 0, torch.rand(C, H) - 0.5, torch.arange(C), cache)
+    xs = torch.rand(T, H) - 0.5
+
+    def prefill():
+        c2 = O.KVCache(1); c2.k[0], c2.v[0] = cache.k[0], cache.v[0]
+        O.qwen2_layer(w, cfg, 0, xs, torch.arange(C, C + T), c2)
+    t_prefill_layer = timed(prefill)
+
+    def decode():
+        c2 = O.KVCache(1); c2.k[0], c2.v[0] = cache.k[0], cache.v[0]
+        O.qwen2_layer(w, cfg, 0, xs[:1], torch.arange(C, C + 1), c2)
+    t_decode_layer = timed(decode, reps=3)
+    t_head = timed(lambda: O.lm_logits(w, xs[0]), reps=3)
+    turn_s = (t_embed + 26 * t_vit_layer + t_proj + 28 * t_prefill_layer + (DECODE_TOKENS - 1) * 28 * t_decode_layer
+              + DECODE_TOKENS * t_head)
+    return {"value": NUM_FUTURE / turn_s, "unit": "action-steps/s", "cores": threads, "kind": "port",
+            "sample": "one steady turn (1 frame, prefill T=212 over C=1676, 5 tokens) at true dims, fp32 torch-CPU oracle: "
+                      "1 ViT layer, projector+pool, 1 LLM layer prefill/decode and lm_head timed and scaled to 26/28 layers "
+                      f"(turn = {turn_s:.2f} s)"}
+
+
+def main():
+    a = parse()
+    from streamvln_amd.config import CONFIGS
+    from streamvln_amd.dist import init_distributed_mode
+    from streamvln_amd.model import StreamVLNForCausalLM
+    from streamvln_amd.eval_harness import reduce_metrics
+    import torch.distributed as dist
+
+    rank, world, local = init_distributed_mode()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP engine has no CPU fallback)"
+    torch.cuda.set_device(local)
+    cfg = CONFIGS[a.config]
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = StreamVLNForCausalLM(cfg, dtype=dtype, device=local, max_envs=1, max_frames=1 + NUM_HISTORY)
+    model.load_synthetic(a.seed)
+    model.model.num_history = NUM_HISTORY
+    model.set_decode_graph(not a.no_graph)
+    run = Runner(model, cfg, rank)
+    lib, h = model._lib, model._h
+    import ctypes as C
+
+    for _ in range(a.warmup):
+        run.turn()
+    d3 = [C.c_double() for _ in range(3)]
+    lib.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 1)
+    if not a.no_probe:
+        lib.svln_probe_reset(h)
+    lat = []
+    model.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    actions0 = run.actions
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        t1 = time.perf_counter()
+        run.turn()
+        lat.append(time.perf_counter() - t1)
+    model.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lib.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 0)
+    roof = None
+    if not a.no_probe:
+        ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+        lib.svln_probe_read(h, C.byref(ms), C.byref(n), C.byref(by))
+        if n.value:
+            avg_s = ms.value / n.value / 1e3
+            ach = by.value / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)", "achieved": round(ach, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                    "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
+    # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
+    summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if world > 1 else "cpu")
+    turns_total = a.steps * world
+    value = NUM_FUTURE * turns_total / dt
+    if rank == 0:
+        out = {
+            "metric": "action-steps/sec (8-frame window, StreamVLN-Qwen-1.5)", "value": round(value, 2), "unit": "action-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: StreamVLN-Qwen-1.5 (SigLIP-so400m + Qwen2-7B, random-init), synthetic 640x480 stream, "
+                                   "8-frame window (num_frames 32 / future 4 / history 8), 5 decode tokens/turn, 1 env per GPU; "
+                                   "step = one model turn = 4 actions", "model_config": a.config, "envs_per_gpu": 1,
+                       "decode_graph": not a.no_graph, "parallelism": f"episode-parallel x{world}"},
+            "per_gpu": round(value / world, 2),
+            "p50_ms_per_turn": round(float(np.median(lat)) * 1e3, 3),
+            "phase_ms_per_turn": {"vision": round(d3[0].value / a.steps, 3), "prefill": round(d3[1].value / a.steps, 3),
+                                  "decode": round(d3[2].value / a.steps, 3)},
+            "metric_allreduce_check": summary,
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(CONFIGS["streamvln_qwen2_7b"])
+        print(json.dumps(out), flush=True)
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

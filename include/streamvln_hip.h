@@ -1,0 +1,105 @@
+/* streamvln_hip.h -- C ABI of the MI355X-native StreamVLN streaming-inference engine.
+ *
+ * The reference has no FFI: its hot path sits behind the Python class
+ * `StreamVLNForCausalLM` (streamvln/model/stream_video_vln.py).  This library is what sits
+ * UNDER a Python class of the same shape (streamvln_amd/model.py); each entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; device pointers are raw HIP
+ * device addresses; no torch types.  All functions return 0 on success, < 0 on error (message
+ * via svln_last_error()).  One engine = one GPU = one HIP stream; not re-entrant per engine.
+ */
+#ifndef STREAMVLN_HIP_H
+#define STREAMVLN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svln_engine svln_engine;
+
+enum { SVLN_BF16 = 0, SVLN_F32 = 1 };
+
+/* Model dimensions (streamvln_amd/config.py; reference: siglip_encoder.py:73-86, Qwen2-7B). */
+typedef struct svln_config {
+    int32_t v_hidden, v_inter, v_heads, v_layers, v_patch, v_image;
+    float v_eps;
+    int32_t hidden, layers, q_heads, kv_heads, head_dim, inter, vocab;
+    float rope_theta, rms_eps;
+    int32_t max_positions;   /* KV / embeds capacity per env (model_max_length, streamvln_eval.py:501) */
+    int32_t max_envs;        /* model.reset(env_num), stream_video_vln.py:473 */
+    int32_t max_frames;      /* views per generate call: 1 + num_history */
+    int32_t dtype;           /* SVLN_BF16 (shipping) or SVLN_F32 (parity mode) */
+} svln_config;
+
+/* -- lifetime: StreamVLNForCausalLM.from_pretrained(...).to(device) (streamvln_eval.py:523-533) -- */
+int svln_create(const svln_config* cfg, int device, svln_engine** out);
+void svln_destroy(svln_engine* h);
+const char* svln_last_error(void);
+int svln_sync(svln_engine* h);
+
+/* -- weights: HF state-dict names (model.layers.N.self_attn.q_proj.weight, ...).
+ * svln_synth_tensor fills a tensor on the device from the counter-based generator of
+ * streamvln_amd/weights.py (seed_t = fnv1a64(name) ^ splitmix64(seed)); svln_set_tensor uploads
+ * a canonical row-major tensor (host or device memory, fp32 or bf16). */
+int svln_synth_tensor(svln_engine* h, const char* name, uint64_t seed_t, float half_width, float base);
+int svln_set_tensor(svln_engine* h, const char* name, const void* data, int dtype, int64_t numel, int on_device);
+int svln_weights_ready(svln_engine* h);            /* 0 when every tensor of the path has been provided */
+int svln_get_tensor_f32(svln_engine* h, const char* name, float* host_out, int64_t numel);   /* canonical order */
+
+/* -- session state: model.reset(env_num) / model.reset_for_env(i) (stream_video_vln.py:473-479);
+ * svln_kv_reset = caller passing past_key_values=None (streamvln_eval.py:349). */
+int svln_reset_env(svln_engine* h, int env);
+int svln_kv_reset(svln_engine* h, int env);
+int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len);
+
+/* -- vision: encode_rgbd (stream_video_vln.py:102-142) minus the memory/image split:
+ * pixels fp32 [F,3,S,S] (device or host) -> F*196 pooled rows kept in the engine's frame buffer. */
+int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device);
+
+/* -- splice: prepare_inputs_labels_for_multimodal (stream_video_vln.py:182-238) for one env.
+ * ids hold text tokens and the sentinels -200 (<image>) / -300 (<memory>); the first n_memory frames
+ * of the last svln_encode_frames call form the memory block, the rest are consumed by <image> in order.
+ * Rows are appended to the env's inputs_embeds (stream_video_vln.py:396-401). */
+int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory);
+
+/* -- greedy generation: StreamVLNForCausalLM.generate -> GenerationMixin (do_sample=False, num_beams=1):
+ * prefill embeds[kv_len:], arg-max, feed generated ids until one is in eos_ids (appended, not fed) or
+ * max_new_tokens; afterwards kv_len = n_embeds + n_out - 1. */
+int svln_generate(svln_engine* h, int env, int max_new_tokens, const int64_t* eos_ids, int n_eos, int64_t* out_ids,
+                  int out_cap, int32_t* n_out);
+/* perf harness variant: decode exactly n_tokens regardless of EOS */
+int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out_ids);
+
+/* -- parity taps (test infrastructure reads these; not used by the product path) */
+int svln_get_hidden(svln_engine* h, float* host_out, int max_rows, int32_t* n_rows);  /* final-norm hidden per generated token of the last generate */
+int svln_get_embeds(svln_engine* h, int env, int start_row, int n_rows, float* host_out);
+int svln_get_frame_feats(svln_engine* h, int start_row, int n_rows, float* host_out);
+int svln_get_top2(svln_engine* h, float* host_out2);
+
+/* -- decode execution mode + timing probes (bench.py) */
+int svln_set_decode_graph(svln_engine* h, int enable);     /* replay the per-token decode step as a hipGraph */
+int svln_probe_reset(svln_engine* h);
+int svln_probe_read(svln_engine* h, double* total_ms, int64_t* launches, double* bytes_per_launch);
+int svln_phase_times(svln_engine* h, double* vision_ms, double* prefill_ms, double* decode_ms, int reset);
+
+/* -- single-kernel entry points (device pointers in the engine dtype) for the op-level parity tests */
+int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res,
+                 int ldr, int res_mod, int M, int N, int K, int epi);
+int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
+                 void* y, int N, int K, int epi, int32_t* host_token);
+int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps);
+int svln_op_layernorm(svln_engine* h, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps);
+/* attention over caller-provided q [T][q_stride] and k/v [S][kv_stride] (engine packs them into pages):
+ * llm: rope = 1 applies RoPE at positions P + i to q and k (head_dim 128, GQA G = nq/nkv, causal)
+ * vit: head_dim 72, non-causal, frames * heads */
+int svln_op_attention_llm(svln_engine* h, void* qkv, int ld, int T, int P, const void* ctx_qkv, int ctx_T, void* out, int o_stride,
+                          int nsplit);
+int svln_op_attention_vit(svln_engine* h, const void* qkv, int ld, int F, void* out, int o_stride);
+int svln_op_pool(svln_engine* h, const void* in, void* out, int F);
+int svln_op_patchify(svln_engine* h, const float* pix, void* out, int F);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -28,21 +28,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from streamvln_amd import weights as Wt                      # noqa: E402
-from streamvln_amd.agent import StreamingAgent                # noqa: E402
-from streamvln_amd.config import TINY, TRUE1                  # noqa: E402
-from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame  # noqa: E402
+from streamvln_amd.synthetic import synthetic_frame          # noqa: E402
 from oracle import ref_harness as RH                          # noqa: E402
 from oracle import streamvln_oracle as O                      # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-SEED = 1234
-
-SCENARIOS = {
-    "tiny_episode": dict(cfg=TINY, steps=36, num_frames=12, nfs=4, num_history=2, max_new=6, eos_mod=3,
-                         lens=(40, 48, 16)),
-    "true1_episode": dict(cfg=TRUE1, steps=12, num_frames=32, nfs=4, num_history=8, max_new=3, eos_mod=0,
-                          lens=(181, 190, 16)),
-}
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from scenarios import SCENARIOS, SEED, run_scenario            # noqa: E402
 
 
 class _RefOut:
@@ -51,6 +43,7 @@ class _RefOut:
         self.past_key_values = cache
         self.hidden = hidden
         self.embeds = embeds
+        self.cache_len = cache.get_seq_length()      # at turn time (the cache object keeps growing)
 
 
 class RefAdapter:
@@ -69,18 +62,10 @@ class RefAdapter:
 
 
 def run(model, sc, tap_embeds):
-    cfg = sc["cfg"]
-    enc = SyntheticPromptEncoder(cfg, seed=7, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
-    eos = tuple(range(sc["eos_mod"] - 1, cfg.vocab, sc["eos_mod"])) if sc["eos_mod"] else ()
-    agent = StreamingAgent(model, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"],
-                           num_history=sc["num_history"], max_new_tokens=sc["max_new"], eos_token_ids=eos,
-                           preprocess=lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb)))
     embeds = []
-    for step in range(sc["steps"]):
-        agent.act(synthetic_frame(0, step))
-        if tap_embeds is not None and agent.turn_log and len(embeds) < len(agent.turn_log):
-            embeds.append(tap_embeds(agent.turn_log[-1]["out"]))
-    return agent.turn_log, embeds
+    log = run_scenario(model, sc, preprocess=lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb)),
+                       on_turn=lambda t, rec: embeds.append(tap_embeds(rec["out"])))
+    return log, embeds
 
 
 def close(a, b, tol=2e-4):
@@ -119,8 +104,8 @@ def main():
             assert r["n_inputs"] == o["n_inputs"] and r["views"] == o["views"]
             assert close(o["out"].hidden, r["out"].hidden), (name, t, "hidden")
             assert close(emb_o[t], emb_r[t]), (name, t, "embeds")
-            cache_len = r["out"].past_key_values.get_seq_length()
-            assert cache_len == len(o["out"].past_key_values)
+            cache_len = r["out"].cache_len
+            assert cache_len == o["out"].cache_len
             e = emb_r[t].numpy()
             fx[f"t{t}_step_id"] = np.int64(r["step_id"])
             fx[f"t{t}_views"] = np.int64(r["views"])

@@ -304,6 +304,7 @@ class GenerateOutput:
         self.past_key_values = past_key_values
         self.hidden = hidden                  # fp32 [n_new, H]: final-norm hidden that produced each token
         self.margins = margins                # top-2 logit margin per generated token
+        self.cache_len = len(past_key_values)  # KV length right after this turn
 
 
 class OracleStreamVLN:

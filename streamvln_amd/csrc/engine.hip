@@ -1,0 +1,779 @@
+// StreamVLN streaming-inference engine: weights, workspaces, paged KV cache, per-env session state,
+// the vision / prefill / decode schedules, and the C ABI of include/streamvln_hip.h.
+//
+// Replaces (reference file:line under /root/reference):
+//   encode_rgbd + vision tower + projector + get_2dPool   streamvln/model/stream_video_vln.py:53-142
+//   prepare_inputs_labels_for_multimodal (splice)         stream_video_vln.py:144-291
+//   generate / prepare_inputs_for_generation / reset*     stream_video_vln.py:353-479
+//   Qwen2 decoder stack + DynamicCache + greedy _sample   transformers 4.45.1 (requirements.txt:140)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/streamvln_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace svln {
+
+static thread_local std::string g_err;
+
+#define HIP_CHECK(x)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess)                                                                          \
+            throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+#define REQUIRE(c, msg)                                          \
+    do {                                                         \
+        if (!(c)) throw std::runtime_error(std::string(msg));    \
+    } while (0)
+
+constexpr int IMAGE_TOKEN = -200, MEMORY_TOKEN = -300;   // streamvln/utils/utils.py:9,15
+constexpr int PAGE = 64;                                 // keys per KV page
+constexpr int HID_TAP_ROWS = 64;
+
+struct Slot {            // canonical tensor -> where its rows live in the packed device layout
+    void* dst; int ld; int64_t rows; int cols; RowMap map; bool filled;
+};
+
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual void synth_tensor(const char* name, uint64_t seed_t, float hw, float base) = 0;
+    virtual void set_tensor(const char* name, const void* data, int dtype, int64_t numel, int on_device) = 0;
+    virtual int weights_missing() = 0;
+    virtual void get_tensor_f32(const char* name, float* out, int64_t numel) = 0;
+    virtual void reset_env(int env) = 0;
+    virtual void kv_reset(int env) = 0;
+    virtual void env_state(int env, int32_t* n_embeds, int32_t* kv_len) = 0;
+    virtual void encode_frames(const float* pixels, int F, int on_device) = 0;
+    virtual void append_turn(int env, const int64_t* ids, int n, int n_memory) = 0;
+    virtual void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) = 0;
+    virtual void get_hidden(float* out, int max_rows, int32_t* n_rows) = 0;
+    virtual void get_embeds(int env, int start, int n, float* out) = 0;
+    virtual void get_feats(int start, int n, float* out) = 0;
+    virtual void get_top2(float* out) = 0;
+    virtual void sync() = 0;
+    virtual void set_graph(int enable) = 0;
+    virtual void probe_reset() = 0;
+    virtual void probe_read(double* ms, int64_t* launches, double* bytes) = 0;
+    virtual void phase_times(double* v, double* p, double* d, int reset) = 0;
+    virtual void op_gemm(const GemmArgs& a) = 0;
+    virtual void op_gemv(GemvArgs a, int32_t* host_token) = 0;
+    virtual void op_rmsnorm(const void* x, const void* g, void* y, int rows, int n, float eps) = 0;
+    virtual void op_layernorm(const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) = 0;
+    virtual void op_attention_llm(void* qkv, int ld, int T, int P, const void* ctx, int ctx_T, void* out, int o_stride, int nsplit) = 0;
+    virtual void op_attention_vit(const void* qkv, int ld, int F, void* out, int o_stride) = 0;
+    virtual void op_pool(const void* in, void* out, int F) = 0;
+    virtual void op_patchify(const float* pix, void* out, int F) = 0;
+};
+
+template <typename T>
+class Engine : public EngineBase {
+public:
+    svln_config c;
+    int device;
+    hipStream_t st = nullptr;
+    std::vector<void*> allocs;
+    std::unordered_map<std::string, Slot> slots;
+
+    // derived dims
+    int Hv, Iv, vheads, vhd, side, S, kp, oside, otok, H, I, nq, nkv, qkv_dim, V;
+    int vhdp, vvrows, vtiles;         // ViT attention geometry
+    int pages_per_env, pages_total;
+
+    struct VLayer { T *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
+    struct LLayer { T *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gu_w, *down_w, *kpool, *vpool; };
+    T *patch_w, *patch_b, *pos_emb, *proj0_w, *proj0_b, *proj2_w, *proj2_b, *embed, *final_norm, *lm_head;
+    std::vector<VLayer> vl;
+    std::vector<LLayer> ll;
+
+    // vision workspaces
+    float* pix = nullptr;
+    T *patches, *vx, *vn, *vqkv, *vattn, *vh, *vkpool, *vvpool, *proj_h, *proj_o, *feats;
+    int n_feat_frames = 0;
+    int* tap_idx; float* tap_w;
+    // llm workspaces
+    T *x, *xn, *qkv, *attn, *hbuf, *hid_tap;
+    float* inv_freq;
+    float* attn_part; int nsplit_max, tiles_per_split;
+    float* part_val; int* part_idx; int* d_token; float* d_top2;
+    int* d_dyn;                  // [0] = position of the token being decoded, [1] = kv_len after it
+    int* d_src; int* h_src;      // splice descriptors
+    int* h_token;                // pinned
+    float* h_top2;
+
+    struct Env {
+        T* embeds = nullptr; int n_embeds = 0; int kv_len = 0;
+        int* d_pages = nullptr; std::vector<int> pages; int n_pages = 0;
+    };
+    std::vector<Env> envs;
+    std::vector<int> free_pages;
+    int n_generated = 0;
+
+    // decode graph + probes
+    bool use_graph = false;
+    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr}; int graph_env = -1;
+    std::vector<hipEvent_t> probe_ev; size_t probe_used = 0; bool probe_on = false; double probe_bytes = 0;
+    hipEvent_t ph_ev[5]; double ph_ms[3] = {0, 0, 0}; bool vision_pending = false;   // v0 v1 p0 p1 d1
+
+    template <typename U> U* dalloc(size_t n, bool zero = false) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, n * sizeof(U) + 256));
+        if (zero) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(U), st));
+        allocs.push_back(p);
+        return (U*)p;
+    }
+    void add_slot(const std::string& name, void* dst, int ld, int64_t rows, int cols, RowMap m = RowMap{1 << 30, 1, 0}) {
+        slots[name] = Slot{dst, ld, rows, cols, m, false};
+    }
+    void add_linear(const std::string& name, T* w, T* b, int out_f, int in_f) {
+        add_slot(name + ".weight", w, in_f, out_f, in_f);
+        if (b) add_slot(name + ".bias", b, out_f, 1, out_f);
+    }
+
+    Engine(const svln_config& cfg, int dev) : c(cfg), device(dev) {
+        HIP_CHECK(hipSetDevice(dev));
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        Hv = c.v_hidden; Iv = c.v_inter; vheads = c.v_heads; vhd = Hv / vheads; side = c.v_image / c.v_patch; S = side * side;
+        kp = ((3 * c.v_patch * c.v_patch + 7) / 8) * 8;
+        oside = (side + 1) / 2; otok = oside * oside;
+        H = c.hidden; I = c.inter; nq = c.q_heads; nkv = c.kv_heads; qkv_dim = (nq + 2 * nkv) * c.head_dim; V = c.vocab;
+        REQUIRE(c.head_dim == 128, "LLM head_dim must be 128");
+        REQUIRE(vhd == 72, "vision head_dim must be 72");
+        REQUIRE(nq % nkv == 0, "q_heads must be a multiple of kv_heads");
+        REQUIRE(H % 8 == 0 && I % 32 == 0 && Hv % 8 == 0 && Iv % 8 == 0, "dims must be multiples of 8 (inter of 32)");
+        REQUIRE(c.max_positions % PAGE == 0, "max_positions must be a multiple of 64");
+        constexpr int EPC = Elt<T>::PER_CHUNK;
+        vhdp = ((((vhd + EPC - 1) / EPC) + 1) & ~1) * EPC;
+        vvrows = ((vhd + 31) / 32) * 32;
+        vtiles = (S + PAGE - 1) / PAGE;
+
+        const std::string VT = "model.vision_tower.vision_tower.vision_model.";
+        patch_w = dalloc<T>((size_t)Hv * kp, true); patch_b = dalloc<T>(Hv); pos_emb = dalloc<T>((size_t)S * Hv);
+        add_slot(VT + "embeddings.patch_embedding.weight", patch_w, kp, Hv, 3 * c.v_patch * c.v_patch);
+        add_slot(VT + "embeddings.patch_embedding.bias", patch_b, Hv, 1, Hv);
+        add_slot(VT + "embeddings.position_embedding.weight", pos_emb, Hv, S, Hv);
+        vl.resize(c.v_layers);
+        for (int i = 0; i < c.v_layers; ++i) {
+            VLayer& L = vl[i];
+            const std::string P = VT + "encoder.layers." + std::to_string(i) + ".";
+            L.ln1_w = dalloc<T>(Hv); L.ln1_b = dalloc<T>(Hv); L.ln2_w = dalloc<T>(Hv); L.ln2_b = dalloc<T>(Hv);
+            L.qkv_w = dalloc<T>((size_t)3 * Hv * Hv); L.qkv_b = dalloc<T>(3 * Hv);
+            L.out_w = dalloc<T>((size_t)Hv * Hv); L.out_b = dalloc<T>(Hv);
+            L.fc1_w = dalloc<T>((size_t)Iv * Hv); L.fc1_b = dalloc<T>(Iv);
+            L.fc2_w = dalloc<T>((size_t)Hv * Iv); L.fc2_b = dalloc<T>(Hv);
+            add_slot(P + "layer_norm1.weight", L.ln1_w, Hv, 1, Hv); add_slot(P + "layer_norm1.bias", L.ln1_b, Hv, 1, Hv);
+            add_slot(P + "layer_norm2.weight", L.ln2_w, Hv, 1, Hv); add_slot(P + "layer_norm2.bias", L.ln2_b, Hv, 1, Hv);
+            add_linear(P + "self_attn.q_proj", L.qkv_w, L.qkv_b, Hv, Hv);
+            add_linear(P + "self_attn.k_proj", L.qkv_w + (size_t)Hv * Hv, L.qkv_b + Hv, Hv, Hv);
+            add_linear(P + "self_attn.v_proj", L.qkv_w + (size_t)2 * Hv * Hv, L.qkv_b + 2 * Hv, Hv, Hv);
+            add_linear(P + "self_attn.out_proj", L.out_w, L.out_b, Hv, Hv);
+            add_linear(P + "mlp.fc1", L.fc1_w, L.fc1_b, Iv, Hv);
+            add_linear(P + "mlp.fc2", L.fc2_w, L.fc2_b, Hv, Iv);
+        }
+        proj0_w = dalloc<T>((size_t)H * Hv); proj0_b = dalloc<T>(H); proj2_w = dalloc<T>((size_t)H * H); proj2_b = dalloc<T>(H);
+        add_linear("model.mm_projector.0", proj0_w, proj0_b, H, Hv);
+        add_linear("model.mm_projector.2", proj2_w, proj2_b, H, H);
+        embed = dalloc<T>((size_t)V * H);
+        add_slot("model.embed_tokens.weight", embed, H, V, H);
+
+        pages_per_env = c.max_positions / PAGE;
+        pages_total = pages_per_env * c.max_envs;
+        ll.resize(c.layers);
+        const int qd = nq * 128, kd = nkv * 128;
+        for (int i = 0; i < c.layers; ++i) {
+            LLayer& L = ll[i];
+            const std::string P = "model.layers." + std::to_string(i) + ".";
+            L.in_norm = dalloc<T>(H); L.post_norm = dalloc<T>(H);
+            L.qkv_w = dalloc<T>((size_t)qkv_dim * H); L.qkv_b = dalloc<T>(qkv_dim);
+            L.o_w = dalloc<T>((size_t)H * qd); L.gu_w = dalloc<T>((size_t)2 * I * H); L.down_w = dalloc<T>((size_t)H * I);
+            L.kpool = dalloc<T>((size_t)pages_total * nkv * PAGE * 128, true);
+            L.vpool = dalloc<T>((size_t)pages_total * nkv * 128 * PAGE, true);
+            add_slot(P + "input_layernorm.weight", L.in_norm, H, 1, H);
+            add_slot(P + "post_attention_layernorm.weight", L.post_norm, H, 1, H);
+            add_linear(P + "self_attn.q_proj", L.qkv_w, L.qkv_b, qd, H);
+            add_linear(P + "self_attn.k_proj", L.qkv_w + (size_t)qd * H, L.qkv_b + qd, kd, H);
+            add_linear(P + "self_attn.v_proj", L.qkv_w + (size_t)(qd + kd) * H, L.qkv_b + qd + kd, kd, H);
+            add_linear(P + "self_attn.o_proj", L.o_w, nullptr, H, qd);
+            add_slot(P + "mlp.gate_proj.weight", L.gu_w, H, I, H, RowMap{32, 2, 0});
+            add_slot(P + "mlp.up_proj.weight", L.gu_w, H, I, H, RowMap{32, 2, 1});
+            add_linear(P + "mlp.down_proj", L.down_w, nullptr, H, I);
+        }
+        final_norm = dalloc<T>(H); lm_head = dalloc<T>((size_t)V * H);
+        add_slot("model.norm.weight", final_norm, H, 1, H);
+        add_slot("lm_head.weight", lm_head, H, V, H);
+
+        // vision workspaces
+        const size_t rv = (size_t)c.max_frames * S;
+        pix = dalloc<float>((size_t)c.max_frames * 3 * c.v_image * c.v_image);
+        patches = dalloc<T>(rv * kp); vx = dalloc<T>(rv * Hv); vn = dalloc<T>(rv * Hv); vqkv = dalloc<T>(rv * 3 * Hv);
+        vattn = dalloc<T>(rv * Hv); vh = dalloc<T>(rv * Iv);
+        vkpool = dalloc<T>((size_t)vtiles * c.max_frames * vheads * PAGE * vhdp, true);
+        vvpool = dalloc<T>((size_t)vtiles * c.max_frames * vheads * vvrows * PAGE, true);
+        proj_h = dalloc<T>(rv * H); proj_o = dalloc<T>(rv * H);
+        feats = dalloc<T>((size_t)c.max_frames * otok * H);
+        {   // bilinear taps: F.interpolate(align_corners=False), scale = side/oside  (stream_video_vln.py:64-67)
+            std::vector<int> ti(2 * oside); std::vector<float> tw(2 * oside);
+            const double scale = (double)side / (double)oside;
+            for (int d = 0; d < oside; ++d) {
+                double src = (d + 0.5) * scale - 0.5; if (src < 0) src = 0;
+                int i0 = (int)std::floor(src); if (i0 > side - 1) i0 = side - 1;
+                int i1 = i0 + 1 < side ? i0 + 1 : side - 1;
+                float l1 = (float)(src - i0);
+                ti[2 * d] = i0; ti[2 * d + 1] = i1; tw[2 * d] = 1.0f - l1; tw[2 * d + 1] = l1;
+            }
+            tap_idx = dalloc<int>(2 * oside); tap_w = dalloc<float>(2 * oside);
+            HIP_CHECK(hipMemcpy(tap_idx, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(tap_w, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        // llm workspaces
+        const size_t rt = (size_t)c.max_positions;
+        x = dalloc<T>(rt * H); xn = dalloc<T>(rt * H); qkv = dalloc<T>(rt * qkv_dim); attn = dalloc<T>(rt * qd); hbuf = dalloc<T>(rt * I);
+        hid_tap = dalloc<T>((size_t)HID_TAP_ROWS * H);
+        {
+            std::vector<float> f(64);
+            for (int j = 0; j < 64; ++j) f[j] = 1.0f / powf(c.rope_theta, (float)(2 * j) / 128.0f);     // modeling_qwen2.py:115
+            inv_freq = dalloc<float>(64);
+            HIP_CHECK(hipMemcpy(inv_freq, f.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+        }
+        tiles_per_split = 2;
+        nsplit_max = (pages_per_env + tiles_per_split - 1) / tiles_per_split;
+        attn_part = dalloc<float>((size_t)nsplit_max * nkv * 32 * 130);
+        part_val = dalloc<float>(2048); part_idx = dalloc<int>(2048);
+        d_token = dalloc<int>(4, true); d_top2 = dalloc<float>(4, true); d_dyn = dalloc<int>(4, true);
+        d_src = dalloc<int>(rt);
+        HIP_CHECK(hipHostMalloc((void**)&h_src, rt * sizeof(int)));
+        HIP_CHECK(hipHostMalloc((void**)&h_token, 16));
+        HIP_CHECK(hipHostMalloc((void**)&h_top2, 16));
+        envs.resize(c.max_envs);
+        for (auto& e : envs) {
+            e.embeds = dalloc<T>(rt * H);
+            e.d_pages = dalloc<int>(pages_per_env, true);
+            e.pages.assign(pages_per_env, 0);
+        }
+        for (int p = pages_total - 1; p >= 0; --p) free_pages.push_back(p);
+        for (int i = 0; i < 5; ++i) HIP_CHECK(hipEventCreate(&ph_ev[i]));
+        HIP_CHECK(hipHostMalloc((void**)&h_dyn, 16));
+        init_kernel_attributes();
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+
+    ~Engine() override {
+        (void)hipStreamSynchronize(st);
+        drop_graphs();
+        for (auto e : probe_ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
+        (void)hipHostFree(h_dyn);
+        for (void* p : allocs) (void)hipFree(p);
+        (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
+        (void)hipStreamDestroy(st);
+    }
+
+    // ------------------------------------------------------------------------------- weights
+    Slot& slot(const char* name) {
+        auto it = slots.find(name);
+        REQUIRE(it != slots.end(), std::string("unknown tensor: ") + name);
+        return it->second;
+    }
+    void synth_tensor(const char* name, uint64_t seed_t, float hw, float base) override {
+        Slot& s = slot(name);
+        launch_synth<T>(st, s.dst, s.ld, s.rows, s.cols, s.map, seed_t, hw, base);
+        s.filled = true;
+    }
+    void set_tensor(const char* name, const void* data, int dtype, int64_t numel, int on_device) override {
+        Slot& s = slot(name);
+        REQUIRE(numel == s.rows * s.cols, std::string("size mismatch for ") + name);
+        const size_t bytes = (size_t)numel * (dtype == SVLN_F32 ? 4 : 2);
+        const void* src = data;
+        void* tmp = nullptr;
+        if (!on_device) {
+            HIP_CHECK(hipMalloc(&tmp, bytes));
+            HIP_CHECK(hipMemcpyAsync(tmp, data, bytes, hipMemcpyHostToDevice, st));
+            src = tmp;
+        }
+        launch_convert<T>(st, s.dst, s.ld, s.rows, s.cols, s.map, src, dtype == SVLN_F32);
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (tmp) HIP_CHECK(hipFree(tmp));
+        s.filled = true;
+    }
+    int weights_missing() override {
+        int n = 0;
+        for (auto& kv : slots) if (!kv.second.filled) { if (!n) g_err = "missing tensor: " + kv.first; ++n; }
+        return n;
+    }
+    void get_tensor_f32(const char* name, float* out, int64_t numel) override {
+        Slot& s = slot(name);
+        REQUIRE(numel == s.rows * s.cols, "size mismatch");
+        std::vector<T> row(s.cols);
+        for (int64_t r = 0; r < s.rows; ++r) {
+            const int64_t dr = (r / s.map.blk) * (int64_t)s.map.blk * s.map.nint + (int64_t)s.map.phase * s.map.blk + r % s.map.blk;
+            HIP_CHECK(hipMemcpy(row.data(), (const T*)s.dst + dr * s.ld, s.cols * sizeof(T), hipMemcpyDeviceToHost));
+            for (int k = 0; k < s.cols; ++k) out[r * s.cols + k] = host_to_f32(row[k]);
+        }
+    }
+    static float host_to_f32(float v) { return v; }
+    static float host_to_f32(bf16 v) {
+        unsigned short b; std::memcpy(&b, &v, 2);
+        uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f;
+    }
+
+    // ------------------------------------------------------------------------------- session
+    Env& env_at(int env) { REQUIRE(env >= 0 && env < (int)envs.size(), "env out of range"); return envs[env]; }
+    void release_pages(Env& e) {
+        for (int i = 0; i < e.n_pages; ++i) free_pages.push_back(e.pages[i]);
+        e.n_pages = 0;
+    }
+    void reset_env(int env) override { Env& e = env_at(env); release_pages(e); e.n_embeds = 0; e.kv_len = 0; }
+    void kv_reset(int env) override { Env& e = env_at(env); release_pages(e); e.kv_len = 0; }
+    void env_state(int env, int32_t* n_embeds, int32_t* kv_len) override { Env& e = env_at(env); *n_embeds = e.n_embeds; *kv_len = e.kv_len; }
+    void ensure_pages(Env& e, int positions) {      // pages covering [0, positions)
+        const int need = (positions + PAGE - 1) / PAGE;
+        REQUIRE(need <= pages_per_env, "sequence exceeds max_positions");
+        if (need <= e.n_pages) return;
+        const int first = e.n_pages;
+        while (e.n_pages < need) {
+            REQUIRE(!free_pages.empty(), "KV page pool exhausted");
+            e.pages[e.n_pages++] = free_pages.back();
+            free_pages.pop_back();
+        }
+        HIP_CHECK(hipMemcpyAsync(e.d_pages + first, e.pages.data() + first, (e.n_pages - first) * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+
+    // ------------------------------------------------------------------------------- vision
+    GemmArgs gemm_args(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
+                       int res_mod, int M, int N, int K, int epi) {
+        GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
+        a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; return a;
+    }
+    AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
+        AttnArgs a; std::memset(&a, 0, sizeof(a));
+        a.Q = q; a.q_stride = ld; a.O = out; a.o_stride = o_stride; a.Kpool = vkpool; a.Vpool = vvpool; a.page_table = nullptr;
+        a.n_kv_total = F * vheads; a.hpf = vheads; a.G = 1; a.T = S; a.P = 0; a.kv_len = S; a.dyn_kv_len = nullptr;
+        a.scale = 1.0f / sqrtf((float)vhd); a.causal = 0; a.nsplit = 1; a.tiles_per_split = vtiles; a.part = nullptr; a.rows_pad = 0;
+        return a;
+    }
+    void vit_attention(const void* qkv_buf, int ld, int F, void* out, int o_stride) {
+        launch_vit_kv_pack<T>(st, qkv_buf, ld, vkpool, vvpool, F, S, vheads, vhd);
+        launch_attention<T>(st, vit_attn_args(qkv_buf, ld, F, out, o_stride), vhd, 4);
+    }
+    void encode_frames(const float* pixels, int F, int on_device) override {
+        REQUIRE(F >= 1 && F <= c.max_frames, "n_frames out of range");
+        REQUIRE(weights_missing() == 0, g_err);
+        const size_t pbytes = (size_t)F * 3 * c.v_image * c.v_image * sizeof(float);
+        HIP_CHECK(hipEventRecord(ph_ev[0], st));
+        HIP_CHECK(hipMemcpyAsync(pix, pixels, pbytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        const int M = F * S;
+        // SigLipVisionEmbeddings (siglip_encoder.py:169-174): patch GEMM + bias + position embedding
+        launch_patchify<T>(st, pix, patches, F, c.v_image, c.v_patch, kp);
+        launch_gemm<T>(st, gemm_args(patches, kp, patch_w, kp, vx, Hv, patch_b, pos_emb, Hv, S, M, Hv, kp, EPI_NONE));
+        for (int i = 0; i < c.v_layers; ++i) {      // SigLipEncoderLayer (siglip_encoder.py:269-305)
+            const VLayer& L = vl[i];
+            launch_layernorm<T>(st, vx, L.ln1_w, L.ln1_b, vn, M, Hv, c.v_eps);
+            launch_gemm<T>(st, gemm_args(vn, Hv, L.qkv_w, Hv, vqkv, 3 * Hv, L.qkv_b, nullptr, 0, 0, M, 3 * Hv, Hv, EPI_NONE));
+            vit_attention(vqkv, 3 * Hv, F, vattn, Hv);
+            launch_gemm<T>(st, gemm_args(vattn, Hv, L.out_w, Hv, vx, Hv, L.out_b, vx, Hv, 0, M, Hv, Hv, EPI_NONE));
+            launch_layernorm<T>(st, vx, L.ln2_w, L.ln2_b, vn, M, Hv, c.v_eps);
+            launch_gemm<T>(st, gemm_args(vn, Hv, L.fc1_w, Hv, vh, Iv, L.fc1_b, nullptr, 0, 0, M, Iv, Hv, EPI_GELU_TANH));
+            launch_gemm<T>(st, gemm_args(vh, Iv, L.fc2_w, Iv, vx, Hv, L.fc2_b, vx, Hv, 0, M, Hv, Iv, EPI_NONE));
+        }
+        // mm_projector (builder.py:41-48) then get_2dPool bilinear 27x27 -> 14x14 (stream_video_vln.py:53-73)
+        launch_gemm<T>(st, gemm_args(vx, Hv, proj0_w, Hv, proj_h, H, proj0_b, nullptr, 0, 0, M, H, Hv, EPI_GELU_ERF));
+        launch_gemm<T>(st, gemm_args(proj_h, H, proj2_w, H, proj_o, H, proj2_b, nullptr, 0, 0, M, H, H, EPI_NONE));
+        launch_pool<T>(st, proj_o, feats, tap_idx, tap_w, F, side, oside, H);
+        HIP_CHECK(hipEventRecord(ph_ev[1], st));
+        vision_pending = true;
+        n_feat_frames = F;
+    }
+
+    // ------------------------------------------------------------------------------- splice
+    void append_turn(int env, const int64_t* ids, int n, int n_memory) override {
+        Env& e = env_at(env);
+        REQUIRE(n_memory >= 0 && n_memory <= n_feat_frames, "n_memory exceeds encoded frames");
+        int rows = 0, img = n_memory, mem_used = 0;
+        const int cap = c.max_positions - e.n_embeds;
+        for (int k = 0; k < n; ++k) {
+            const int64_t t = ids[k];
+            if (t == IMAGE_TOKEN) {
+                REQUIRE(img < n_feat_frames, "more <image> tokens than encoded frames");
+                REQUIRE(rows + otok <= cap, "inputs_embeds exceeds max_positions");
+                for (int j = 0; j < otok; ++j) h_src[rows++] = -(1 + img * otok + j);
+                ++img;
+            } else if (t == MEMORY_TOKEN) {
+                REQUIRE(n_memory > 0 && mem_used == 0, "<memory> token without (or with repeated) memory frames");
+                REQUIRE(rows + n_memory * otok <= cap, "inputs_embeds exceeds max_positions");
+                for (int j = 0; j < n_memory * otok; ++j) h_src[rows++] = -(1 + j);
+                mem_used = 1;
+            } else {
+                REQUIRE(t >= 0 && t < V, "token id out of range");
+                REQUIRE(rows + 1 <= cap, "inputs_embeds exceeds max_positions");
+                h_src[rows++] = (int)t;
+            }
+        }
+        HIP_CHECK(hipMemcpyAsync(d_src, h_src, rows * sizeof(int), hipMemcpyHostToDevice, st));
+        launch_gather_rows<T>(st, d_src, embed, feats, e.embeds + (size_t)e.n_embeds * H, rows, H);
+        HIP_CHECK(hipStreamSynchronize(st));         // h_src is reused by the next call
+        e.n_embeds += rows;
+    }
+
+    // ------------------------------------------------------------------------------- LLM
+    AttnArgs llm_attn_args(const LLayer& L, const Env& e, const void* q, int ld, void* out, int o_stride, int Tn, int P, int kv_len,
+                           bool decode) {
+        AttnArgs a; std::memset(&a, 0, sizeof(a));
+        a.Q = q; a.q_stride = ld; a.O = out; a.o_stride = o_stride; a.Kpool = L.kpool; a.Vpool = L.vpool; a.page_table = e.d_pages;
+        a.n_kv_total = nkv; a.hpf = nkv; a.G = nq / nkv; a.T = Tn; a.P = P; a.kv_len = kv_len; a.scale = 1.0f / sqrtf(128.0f);
+        a.part = attn_part; a.rows_pad = 32;
+        if (decode) {
+            a.causal = 0; a.dyn_kv_len = d_dyn + 1; a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
+        } else {
+            a.causal = 1; a.dyn_kv_len = nullptr; a.nsplit = 1; a.tiles_per_split = pages_per_env;
+        }
+        return a;
+    }
+
+    void prefill(Env& e, int P, int Tn) {
+        HIP_CHECK(hipMemcpyAsync(x, e.embeds + (size_t)P * H, (size_t)Tn * H * sizeof(T), hipMemcpyDeviceToDevice, st));
+        const int qd = nq * 128;
+        for (int i = 0; i < c.layers; ++i) {       // Qwen2DecoderLayer (modeling_qwen2.py:269-299)
+            const LLayer& L = ll[i];
+            launch_rmsnorm<T>(st, x, L.in_norm, xn, Tn, H, c.rms_eps);
+            launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, Tn, qkv_dim, H, EPI_NONE));
+            RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq;
+            r.T = Tn; r.nq = nq; r.nkv = nkv; r.P = P; r.dyn_pos = nullptr;
+            launch_rope_kv<T>(st, r);
+            launch_attention<T>(st, llm_attn_args(L, e, qkv, qkv_dim, attn, qd, Tn, P, P + Tn, false), 128, 4);
+            launch_gemm<T>(st, gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, Tn, H, qd, EPI_NONE));
+            launch_rmsnorm<T>(st, x, L.post_norm, xn, Tn, H, c.rms_eps);
+            launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, Tn, 2 * I, H, EPI_SWIGLU));
+            launch_gemm<T>(st, gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, Tn, H, I, EPI_NONE));
+        }
+    }
+
+    GemvArgs gemv_args(const void* W, int ldw, const void* xin, const void* norm_w, const void* bias, const void* res, void* y, int N, int K,
+                       int epi) {
+        GemvArgs a; a.W = W; a.ldw = ldw; a.x = xin; a.norm_w = norm_w; a.eps = c.rms_eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K;
+        a.epi = epi; a.part_val = part_val; a.part_idx = part_idx; return a;
+    }
+    // final norm -> hidden tap row -> lm_head arg-max -> d_token  (lm_head on the LAST position only)
+    void head(const T* xrow, int tap_row) {
+        T* tap = hid_tap + (size_t)(tap_row < HID_TAP_ROWS ? tap_row : HID_TAP_ROWS - 1) * H;
+        launch_rmsnorm<T>(st, xrow, final_norm, tap, 1, H, c.rms_eps);
+        launch_gemv<T>(st, gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX));
+        launch_argmax_final(st, part_val, part_idx, gemv_grid(V), d_token, d_top2);
+    }
+    // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_dyn,
+    // d_token) so any sub-range [lo, hi) of the sequence can be captured once and graph-replayed.
+    // Op ids: 0 = embedding gather, then 7 per layer; the layer-0 gate/up GEMV is op PROBE_OP.
+    static constexpr int OPS_PER_LAYER = 7, PROBE_OP = 1 + 5;
+    int total_ops() const { return 1 + c.layers * OPS_PER_LAYER; }
+    void decode_ops(Env& e, int lo, int hi) {
+        const int qd = nq * 128;
+        int op = 0;
+        auto on = [&](void) { const bool r = op >= lo && op < hi; ++op; return r; };
+        if (on()) launch_gather_rows<T>(st, d_token, embed, feats, x, 1, H);
+        for (int i = 0; i < c.layers; ++i) {
+            const LLayer& L = ll[i];
+            if (on()) launch_gemv<T>(st, gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE));
+            if (on()) {
+                RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq;
+                r.T = 1; r.nq = nq; r.nkv = nkv; r.P = 0; r.dyn_pos = d_dyn;
+                launch_rope_kv<T>(st, r);
+            }
+            AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, 1, 0, 0, true);
+            if (on()) launch_attention<T>(st, a, 128, 1);
+            if (on()) launch_attention_combine<T>(st, a, 128);
+            if (on()) launch_gemv<T>(st, gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE));
+            if (on()) launch_gemv<T>(st, gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU));
+            if (on()) launch_gemv<T>(st, gemv_args(L.down_w, I, hbuf, nullptr, nullptr, x, x, H, I, EPI_NONE));
+        }
+    }
+
+    int* h_dyn = nullptr;        // pinned
+    void set_dyn(int pos) {
+        h_dyn[0] = pos; h_dyn[1] = pos + 1;     // safe to overwrite: the previous step's copy completed before read_token returned
+        HIP_CHECK(hipMemcpyAsync(d_dyn, h_dyn, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+
+    hipGraphExec_t capture(Env& e, int lo, int hi) {
+        hipGraph_t g; hipGraphExec_t ex;
+        HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        decode_ops(e, lo, hi);
+        HIP_CHECK(hipStreamEndCapture(st, &g));
+        HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(g));
+        return ex;
+    }
+    void drop_graphs() {
+        for (auto& g : graph_exec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        graph_env = -1;
+    }
+    // HIP events bracket the layer-0 gate/up GEMV (launched directly between two captured halves) while probing;
+    // that launch is the same kernel, grid and bytes as the other layers' gate/up GEMVs inside the graph.
+    void decode_step(Env& e, int env, int tap_row) {
+        ensure_pages(e, e.kv_len + 1);           // the fed token sits at position kv_len
+        set_dyn(e.kv_len);
+        const int n_ops = total_ops();
+        const bool probing = probe_on && probe_used + 2 <= probe_ev.size();
+        if (use_graph) {
+            if (graph_env != env) {
+                drop_graphs();
+                graph_exec[0] = capture(e, 0, n_ops);
+                graph_exec[1] = capture(e, 0, PROBE_OP);
+                graph_exec[2] = capture(e, PROBE_OP + 1, n_ops);
+                graph_env = env;
+            }
+            if (!probing) {
+                HIP_CHECK(hipGraphLaunch(graph_exec[0], st));
+            } else {
+                HIP_CHECK(hipGraphLaunch(graph_exec[1], st));
+                HIP_CHECK(hipEventRecord(probe_ev[probe_used], st));
+                decode_ops(e, PROBE_OP, PROBE_OP + 1);
+                HIP_CHECK(hipEventRecord(probe_ev[probe_used + 1], st));
+                HIP_CHECK(hipGraphLaunch(graph_exec[2], st));
+                probe_used += 2;
+            }
+        } else if (!probing) {
+            decode_ops(e, 0, n_ops);
+        } else {
+            decode_ops(e, 0, PROBE_OP);
+            HIP_CHECK(hipEventRecord(probe_ev[probe_used], st));
+            decode_ops(e, PROBE_OP, PROBE_OP + 1);
+            HIP_CHECK(hipEventRecord(probe_ev[probe_used + 1], st));
+            decode_ops(e, PROBE_OP + 1, n_ops);
+            probe_used += 2;
+        }
+        head(x, tap_row);
+        e.kv_len += 1;
+    }
+
+    int read_token() {
+        HIP_CHECK(hipMemcpyAsync(h_token, d_token, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h_top2, d_top2, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return h_token[0];
+    }
+
+    void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) override {
+        Env& e = env_at(env);
+        REQUIRE(weights_missing() == 0, g_err);
+        const int P = e.kv_len, L = e.n_embeds, Tn = L - P;
+        REQUIRE(Tn >= 1, "nothing to prefill: inputs_embeds not longer than the KV cache");
+        REQUIRE(max_new >= 1 && cap >= 1, "max_new_tokens must be >= 1");
+        ensure_pages(e, L);
+        HIP_CHECK(hipEventRecord(ph_ev[2], st));
+        prefill(e, P, Tn);
+        head(x + (size_t)(Tn - 1) * H, 0);
+        e.kv_len = L;
+        HIP_CHECK(hipEventRecord(ph_ev[3], st));
+        int n = 0;
+        while (true) {
+            const int tok = read_token();       // synchronises the stream
+            if (n == 0) {
+                float t = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[1] += t;
+                if (vision_pending) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
+            }
+            if (n < cap) out[n] = tok;
+            ++n;
+            bool stop = n >= max_new || n >= cap;
+            if (!fixed) for (int k = 0; k < n_eos; ++k) if (eos[k] == tok) stop = true;
+            if (stop) break;
+            REQUIRE(e.kv_len + 1 <= c.max_positions, "sequence exceeds max_positions during decode");
+            decode_step(e, env, n);
+        }
+        if (n > 1) {
+            float t = 0.f;
+            HIP_CHECK(hipEventRecord(ph_ev[4], st));
+            HIP_CHECK(hipEventSynchronize(ph_ev[4]));
+            HIP_CHECK(hipEventElapsedTime(&t, ph_ev[3], ph_ev[4])); ph_ms[2] += t;
+        }
+        n_generated = n;
+        *n_out = n;
+    }
+
+    // ------------------------------------------------------------------------------- taps
+    void read_rows_f32(const T* src, size_t n, float* out) {
+        float* tmp = nullptr;
+        HIP_CHECK(hipMalloc((void**)&tmp, n * sizeof(float)));
+        launch_to_f32<T>(st, src, tmp, (int64_t)n);
+        HIP_CHECK(hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipFree(tmp));
+    }
+    void get_hidden(float* out, int max_rows, int32_t* n_rows) override {
+        int n = n_generated < HID_TAP_ROWS ? n_generated : HID_TAP_ROWS;
+        if (n > max_rows) n = max_rows;
+        read_rows_f32(hid_tap, (size_t)n * H, out);
+        *n_rows = n;
+    }
+    void get_embeds(int env, int start, int n, float* out) override {
+        Env& e = env_at(env);
+        REQUIRE(start >= 0 && n >= 0 && start + n <= e.n_embeds, "embeds range");
+        read_rows_f32(e.embeds + (size_t)start * H, (size_t)n * H, out);
+    }
+    void get_feats(int start, int n, float* out) override {
+        REQUIRE(start >= 0 && n >= 0 && start + n <= n_feat_frames * otok, "feats range");
+        read_rows_f32(feats + (size_t)start * H, (size_t)n * H, out);
+    }
+    void get_top2(float* out) override { out[0] = h_top2[0]; out[1] = h_top2[1]; }
+    void sync() override { HIP_CHECK(hipStreamSynchronize(st)); }
+    void set_graph(int enable) override { use_graph = enable != 0; if (!use_graph) drop_graphs(); }
+    void probe_reset() override {
+        if (probe_ev.empty()) { probe_ev.resize(4096); for (auto& ev : probe_ev) HIP_CHECK(hipEventCreate(&ev)); }
+        probe_used = 0; probe_on = true;
+        probe_bytes = (double)2 * I * H * sizeof(T);
+    }
+    void probe_read(double* ms, int64_t* launches, double* bytes) override {
+        HIP_CHECK(hipStreamSynchronize(st));
+        double tot = 0;
+        for (size_t k = 0; k + 1 < probe_used; k += 2) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, probe_ev[k], probe_ev[k + 1])); tot += t; }
+        *ms = tot; *launches = (int64_t)(probe_used / 2); *bytes = probe_bytes;
+        probe_on = false;
+    }
+    void phase_times(double* v, double* p, double* d, int reset) override {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (vision_pending) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
+        *v = ph_ms[0]; *p = ph_ms[1]; *d = ph_ms[2];
+        if (reset) ph_ms[0] = ph_ms[1] = ph_ms[2] = 0;
+    }
+
+    // ------------------------------------------------------------------------------- op-level entry points
+    void op_gemm(const GemmArgs& a) override { launch_gemm<T>(st, a); sync(); }
+    void op_gemv(GemvArgs a, int32_t* host_token) override {
+        a.part_val = part_val; a.part_idx = part_idx;
+        launch_gemv<T>(st, a);
+        if (a.epi == EPI_ARGMAX) {
+            launch_argmax_final(st, part_val, part_idx, gemv_grid(a.N), d_token, d_top2);
+            const int t = read_token();
+            if (host_token) *host_token = t;
+        }
+        sync();
+    }
+    void op_rmsnorm(const void* xi, const void* g, void* y, int rows, int n, float eps) override { launch_rmsnorm<T>(st, xi, g, y, rows, n, eps); sync(); }
+    void op_layernorm(const void* xi, const void* g, const void* b, void* y, int rows, int n, float eps) override {
+        launch_layernorm<T>(st, xi, g, b, y, rows, n, eps); sync();
+    }
+    // LLM attention on layer-0 pools / env 0: context rows (ctx_T positions from 0) are roped + appended first, then the T new rows
+    void op_attention_llm(void* qkv_new, int ld, int Tn, int P, const void* ctx, int ctx_T, void* out, int o_stride, int nsplit) override {
+        Env& e = env_at(0);
+        REQUIRE(ctx_T == P, "context length must equal P");
+        reset_env(0);
+        ensure_pages(e, P + Tn);
+        const LLayer& L = ll[0];
+        RopeKvArgs r; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq; r.nq = nq; r.nkv = nkv; r.dyn_pos = nullptr;
+        r.ld = ld;
+        if (ctx_T > 0) { r.qkv = const_cast<void*>(ctx); r.T = ctx_T; r.P = 0; launch_rope_kv<T>(st, r); }
+        r.qkv = qkv_new; r.T = Tn; r.P = P; launch_rope_kv<T>(st, r);
+        AttnArgs a = llm_attn_args(L, e, qkv_new, ld, out, o_stride, Tn, P, P + Tn, false);
+        if (nsplit > 1) {
+            REQUIRE(Tn * (nq / nkv) <= 32, "split-KV path takes at most 32 rows per kv head");
+            a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
+            launch_attention<T>(st, a, 128, 1);
+            launch_attention_combine<T>(st, a, 128);
+        } else {
+            launch_attention<T>(st, a, 128, 4);
+        }
+        sync();
+        reset_env(0);
+    }
+    void op_attention_vit(const void* qkv_buf, int ld, int F, void* out, int o_stride) override {
+        REQUIRE(F >= 1 && F <= c.max_frames, "frames");
+        vit_attention(qkv_buf, ld, F, out, o_stride); sync();
+    }
+    void op_pool(const void* in, void* out, int F) override { launch_pool<T>(st, in, out, tap_idx, tap_w, F, side, oside, H); sync(); }
+    void op_patchify(const float* p, void* out, int F) override { launch_patchify<T>(st, p, out, F, c.v_image, c.v_patch, kp); sync(); }
+};
+
+}  // namespace svln
+
+// =================================================================================== C ABI
+using namespace svln;
+struct svln_engine { EngineBase* impl; };
+
+#define API_BEGIN try {
+#define API_END                                   \
+    return 0;                                     \
+    }                                             \
+    catch (const std::exception& ex) {            \
+        g_err = ex.what();                        \
+        return -1;                                \
+    }
+
+extern "C" {
+
+const char* svln_last_error(void) { return g_err.c_str(); }
+
+int svln_create(const svln_config* cfg, int device, svln_engine** out) {
+    API_BEGIN
+    REQUIRE(cfg && out, "null argument");
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    REQUIRE(n > 0 && device < n, "no such HIP device");
+    svln_engine* h = new svln_engine;
+    if (cfg->dtype == SVLN_F32) h->impl = new Engine<float>(*cfg, device);
+    else h->impl = new Engine<bf16>(*cfg, device);
+    *out = h;
+    API_END
+}
+void svln_destroy(svln_engine* h) { if (h) { delete h->impl; delete h; } }
+int svln_sync(svln_engine* h) { API_BEGIN h->impl->sync(); API_END }
+int svln_synth_tensor(svln_engine* h, const char* name, uint64_t seed_t, float hw, float base) { API_BEGIN h->impl->synth_tensor(name, seed_t, hw, base); API_END }
+int svln_set_tensor(svln_engine* h, const char* name, const void* data, int dtype, int64_t numel, int on_device) {
+    API_BEGIN h->impl->set_tensor(name, data, dtype, numel, on_device); API_END
+}
+int svln_weights_ready(svln_engine* h) { API_BEGIN if (h->impl->weights_missing()) return -2; API_END }
+int svln_get_tensor_f32(svln_engine* h, const char* name, float* out, int64_t numel) { API_BEGIN h->impl->get_tensor_f32(name, out, numel); API_END }
+int svln_reset_env(svln_engine* h, int env) { API_BEGIN h->impl->reset_env(env); API_END }
+int svln_kv_reset(svln_engine* h, int env) { API_BEGIN h->impl->kv_reset(env); API_END }
+int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len) { API_BEGIN h->impl->env_state(env, n_embeds, kv_len); API_END }
+int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device) { API_BEGIN h->impl->encode_frames(pixels, n_frames, on_device); API_END }
+int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory) { API_BEGIN h->impl->append_turn(env, ids, n_ids, n_memory); API_END }
+int svln_generate(svln_engine* h, int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) {
+    API_BEGIN h->impl->generate(env, max_new, eos, n_eos, out, cap, n_out, false); API_END
+}
+int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out) {
+    API_BEGIN int32_t n = 0; h->impl->generate(env, n_tokens, nullptr, 0, out, n_tokens, &n, true); API_END
+}
+int svln_get_hidden(svln_engine* h, float* out, int max_rows, int32_t* n_rows) { API_BEGIN h->impl->get_hidden(out, max_rows, n_rows); API_END }
+int svln_get_embeds(svln_engine* h, int env, int start, int n, float* out) { API_BEGIN h->impl->get_embeds(env, start, n, out); API_END }
+int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEGIN h->impl->get_feats(start, n, out); API_END }
+int svln_get_top2(svln_engine* h, float* out) { API_BEGIN h->impl->get_top2(out); API_END }
+int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN h->impl->set_graph(enable); API_END }
+int svln_probe_reset(svln_engine* h) { API_BEGIN h->impl->probe_reset(); API_END }
+int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN h->impl->probe_read(ms, launches, bytes); API_END }
+int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN h->impl->phase_times(v, p, d, reset); API_END }
+
+int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
+                 int res_mod, int M, int N, int K, int epi) {
+    API_BEGIN
+    GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
+    a.M = M; a.N = N; a.K = K; a.epi = epi;
+    h->impl->op_gemm(a);
+    API_END
+}
+int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res, void* y,
+                 int N, int K, int epi, int32_t* host_token) {
+    API_BEGIN
+    GemvArgs a; a.W = W; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
+    a.part_val = nullptr; a.part_idx = nullptr;
+    h->impl->op_gemv(a, host_token);
+    API_END
+}
+int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps) { API_BEGIN h->impl->op_rmsnorm(x, g, y, rows, n, eps); API_END }
+int svln_op_layernorm(svln_engine* h, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) {
+    API_BEGIN h->impl->op_layernorm(x, g, b, y, rows, n, eps); API_END
+}
+int svln_op_attention_llm(svln_engine* h, void* qkv, int ld, int T, int P, const void* ctx, int ctx_T, void* out, int o_stride, int nsplit) {
+    API_BEGIN h->impl->op_attention_llm(qkv, ld, T, P, ctx, ctx_T, out, o_stride, nsplit); API_END
+}
+int svln_op_attention_vit(svln_engine* h, const void* qkv, int ld, int F, void* out, int o_stride) { API_BEGIN h->impl->op_attention_vit(qkv, ld, F, out, o_stride); API_END }
+int svln_op_pool(svln_engine* h, const void* in, void* out, int F) { API_BEGIN h->impl->op_pool(in, out, F); API_END }
+int svln_op_patchify(svln_engine* h, const float* pix, void* out, int F) { API_BEGIN h->impl->op_patchify(pix, out, F); API_END }
+
+}  // extern "C"

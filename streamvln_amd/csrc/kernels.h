@@ -1,0 +1,116 @@
+// Host-side launch interface of the hand-written gfx950 kernels.  One launcher per kernel,
+// each instantiated for T = bf16 (shipping) and T = float (parity mode).  Launchers only
+// enqueue on `stream` (no allocation, no sync) so a caller may capture them in a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svln {
+
+enum Epi : int { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4 };
+
+// C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]) + res[row % res_mod or row][N]      (all T, fp32 accumulate)
+// K, lda, ldw multiples of one 16-byte chunk; EPI_SWIGLU: W rows are 32-row blocks
+// [gate 32 | up 32] and C is [M, N/2] = silu(gate) * up.
+struct GemmArgs {
+    const void* A; int lda;
+    const void* W; int ldw;
+    void* C; int ldc;
+    const void* bias;
+    const void* res; int ldr; int res_mod;
+    int M, N, K;
+    int epi;
+};
+template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a);
+
+// y[N] = epi(W[N,K] . x'[K] + bias) + res,  x' = x or rmsnorm(x) * norm_w (fused prologue).
+// EPI_SWIGLU as above (y has N/2 entries).  EPI_ARGMAX: no y; per-workgroup (max, lowest index)
+// partials go to part_val/part_idx, reduced by launch_argmax_final.
+struct GemvArgs {
+    const void* W; int ldw;
+    const void* x;
+    const void* norm_w; float eps;
+    const void* bias;
+    const void* res;
+    void* y;
+    int N, K;
+    int epi;
+    float* part_val; int* part_idx;
+};
+template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
+int gemv_grid(int N);                       // workgroups launch_gemv uses for N rows
+void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token,
+                         float* out_top /*[2]: best, runner-up of partial maxima (diagnostic)*/);
+
+// Flash-style attention over paged K / V^T tiles (64 keys per page).
+//   pools:  K  [page][n_kv_total][64][HDP]        HDP = head dim padded to an even chunk count
+//           Vt [page][n_kv_total][DT*32][64]      DT = ceil(HD/32); transposed so keys are contiguous
+//   rows of one "kv head" kh: rho = i*G + g  (query position i, q-head g of the group)
+//   Q/O element (frame, i, head, d) at  ((frame*T + i) * stride) + head*HD + d, head = (kh % hpf)*G + g
+struct AttnArgs {
+    const void* Q; int q_stride;
+    void* O; int o_stride;
+    const void* Kpool; const void* Vpool;
+    const int* page_table;        // device [tiles]; null = identity
+    int n_kv_total, hpf, G, T;
+    int P;                        // absolute position of query 0 (causal mask: key <= P + i)
+    int kv_len;
+    const int* dyn_kv_len;        // device scalar overriding kv_len (P = kv_len - T); for hipGraph replay
+    float scale;
+    int causal;
+    int nsplit, tiles_per_split;  // split-KV: gridDim.z = nsplit, partials in `part`
+    float* part;                  // [nsplit][n_kv_total][rows_pad][HD + 2] fp32 (O unnormalised, m, l)
+    int rows_pad;
+};
+template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves);
+template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);
+
+// RMSNorm / LayerNorm over rows of length n (T in, T out).
+template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps);
+template <typename T> void launch_layernorm(hipStream_t s, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps);
+
+// RoPE on q,k (in place on q) + append roped k and v to the paged cache.
+// qkv: [T][(nq + 2 nkv) * 128]; positions P + i (P = *dyn_pos if given).
+struct RopeKvArgs {
+    void* qkv; int ld;
+    void* Kpool; void* Vpool;
+    const int* page_table;
+    const float* inv_freq;        // [64]
+    int T, nq, nkv, P;
+    const int* dyn_pos;
+};
+template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a);
+
+// ViT: qkv [F*S][3*Hv] -> K pages [page][F*heads][64][HDP], Vt pages [page][F*heads][96][64]
+template <typename T> void launch_vit_kv_pack(hipStream_t s, const void* qkv, int ld, void* Kpool, void* Vpool, int F, int S,
+                                             int heads, int head_dim);
+
+// pixels [F,3,S,S] (fp32) -> patches [F*side*side][kp] (T), k = c*p*p + ky*p + kx, zero padded to kp
+template <typename T> void launch_patchify(hipStream_t s, const float* pix, void* out, int F, int image, int patch, int kp);
+
+// bilinear 2-D pooling of token grids: in [F][side*side][C] -> out [F][out*out][C]
+// taps: device int2/float2 tables [out] (i0,i1) and (w0,w1), shared by both axes.
+template <typename T> void launch_pool(hipStream_t s, const void* in, void* out, const int* tap_idx, const float* tap_w, int F,
+                                       int side, int out_side, int C);
+
+// out[r][:] = src[r] >= 0 ? embed[src[r]][:] : feats[-(src[r]+1)][:]
+template <typename T> void launch_gather_rows(hipStream_t s, const int* src, const void* embed, const void* feats, void* out,
+                                              int rows, int n);
+
+// weights: synthesize (see weights.py) or convert canonical rows into packed rows
+// dst row = (r / blk) * blk * nint + phase * blk + r % blk ; cols copied to [0, cols), dst_ld >= cols
+struct RowMap { int blk, nint, phase; };
+template <typename T> void launch_synth(hipStream_t s, void* dst, int dst_ld, int64_t rows, int cols, RowMap m, uint64_t seed_t,
+                                        float half_width, float base);
+template <typename T> void launch_convert(hipStream_t s, void* dst, int dst_ld, int64_t rows, int cols, RowMap m, const void* src,
+                                          int src_is_f32);
+template <typename T> void launch_to_f32(hipStream_t s, const void* src, float* dst, int64_t n);
+template <typename T> void launch_from_f32(hipStream_t s, const float* src, void* dst, int64_t n);
+
+// raise the dynamic-LDS limit of the kernels that may ask for more than 64 KiB (call once, outside capture)
+void gemm_init_attrs();
+void gemv_init_attrs();
+void attention_init_attrs();
+inline void init_kernel_attributes() { gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); }
+
+}  // namespace svln

@@ -1,0 +1,289 @@
+// Bandwidth-bound helper kernels of the path (norms, RoPE + KV append, ViT K/V packing,
+// patch extraction, bilinear token pooling, embedding splice, weight synthesis / conversion).
+// All of them are HBM/L2-bound byte movers: 16-byte vector accesses, one wave per row where a
+// row reduction is needed, no LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace svln {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ norms
+// one wave per row; three cached passes (the row stays in L1/L2): statistics in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* g, T* y, int rows, int n, float eps) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * n;
+    T* yr = y + (size_t)row * n;
+    const int nch = n / EPC;
+    float ss = 0.0f;
+    for (int ci = lane; ci < nch; ci += 64) {
+        float f[EPC];
+        chunk_to_f32<T>(*(const uint4*)(xr + (size_t)ci * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) ss += f[e] * f[e];
+    }
+    ss = wave_sum(ss);
+    const float sc = rsqrtf(ss / (float)n + eps);
+    for (int ci = lane; ci < nch; ci += 64) {
+        float f[EPC], gf[EPC];
+        chunk_to_f32<T>(*(const uint4*)(xr + (size_t)ci * EPC), f);
+        chunk_to_f32<T>(*(const uint4*)(g + (size_t)ci * EPC), gf);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = gf[e] * (f[e] * sc);
+        *(uint4*)(yr + (size_t)ci * EPC) = f32_to_chunk<T>(f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const T* g, const T* b, T* y, int rows, int n, float eps) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * n;
+    T* yr = y + (size_t)row * n;
+    const int nch = n / EPC;
+    float s = 0.0f;
+    for (int ci = lane; ci < nch; ci += 64) {
+        float f[EPC];
+        chunk_to_f32<T>(*(const uint4*)(xr + (size_t)ci * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s += f[e];
+    }
+    const float mu = wave_sum(s) / (float)n;
+    float v = 0.0f;
+    for (int ci = lane; ci < nch; ci += 64) {
+        float f[EPC];
+        chunk_to_f32<T>(*(const uint4*)(xr + (size_t)ci * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v += (f[e] - mu) * (f[e] - mu);
+    }
+    const float sc = rsqrtf(wave_sum(v) / (float)n + eps);
+    for (int ci = lane; ci < nch; ci += 64) {
+        float f[EPC], gf[EPC], bf[EPC];
+        chunk_to_f32<T>(*(const uint4*)(xr + (size_t)ci * EPC), f);
+        chunk_to_f32<T>(*(const uint4*)(g + (size_t)ci * EPC), gf);
+        chunk_to_f32<T>(*(const uint4*)(b + (size_t)ci * EPC), bf);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mu) * sc * gf[e] + bf[e];
+        *(uint4*)(yr + (size_t)ci * EPC) = f32_to_chunk<T>(f);
+    }
+}
+
+// --------------------------------------------------------------------------------- RoPE + KV append
+// grid (T, nq + nkv + nkv), 64 threads: lane d pairs (d, d + 64) of a 128-wide head.
+// q heads: rotate in place.  k heads: rotate, write K page row.  v heads: write transposed Vt page.
+template <typename T>
+__global__ __launch_bounds__(64) void rope_kv_kernel(RopeKvArgs p) {
+    const int i = blockIdx.x, hd = blockIdx.y, d = threadIdx.x;
+    const int P = p.dyn_pos ? *p.dyn_pos : p.P;
+    const int pos = P + i;
+    T* row = (T*)p.qkv + (size_t)i * p.ld + (size_t)hd * 128;
+    const float x1 = to_f32(row[d]), x2 = to_f32(row[d + 64]);
+    const int page = p.page_table[pos >> 6], off = pos & 63;
+    if (hd < p.nq + p.nkv) {
+        const float ang = (float)pos * p.inv_freq[d];
+        const float c = cosf(ang), s = sinf(ang);
+        const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;     // q*cos + rotate_half(q)*sin
+        if (hd < p.nq) {
+            row[d] = from_f32<T>(o1);
+            row[d + 64] = from_f32<T>(o2);
+        } else {
+            const int kh = hd - p.nq;
+            T* kr = (T*)p.Kpool + (((size_t)page * p.nkv + kh) * 64 + off) * 128;
+            kr[d] = from_f32<T>(o1);
+            kr[d + 64] = from_f32<T>(o2);
+        }
+    } else {
+        const int kh = hd - p.nq - p.nkv;
+        T* vt = (T*)p.Vpool + ((size_t)page * p.nkv + kh) * 128 * 64;
+        vt[(size_t)d * 64 + off] = from_f32<T>(x1);
+        vt[(size_t)(d + 64) * 64 + off] = from_f32<T>(x2);
+    }
+}
+
+// ViT K/V packing: qkv [F*S][3*Hv] -> K pages [tile][F*heads][64][HDP] (zero padded), Vt [tile][F*heads][VROWS][64]
+template <typename T>
+__global__ __launch_bounds__(256) void vit_kv_pack_kernel(const T* qkv, int ld, T* Kpool, T* Vpool, int F, int S, int heads, int HD,
+                                                          int HDP, int VROWS) {
+    const int tile = blockIdx.x, kh = blockIdx.y;          // kh = f*heads + head
+    const int f = kh / heads, head = kh % heads, Hv = heads * HD;
+    const int nkv = F * heads;
+    T* kp = Kpool + ((size_t)tile * nkv + kh) * 64 * HDP;
+    T* vp = Vpool + ((size_t)tile * nkv + kh) * VROWS * 64;
+    for (int e = threadIdx.x; e < 64 * HDP; e += 256) {
+        const int key = e / HDP, d = e % HDP, s = tile * 64 + key;
+        T v = from_f32<T>(0.0f);
+        if (s < S && d < HD) v = qkv[(size_t)(f * S + s) * ld + Hv + head * HD + d];
+        kp[e] = v;
+    }
+    for (int e = threadIdx.x; e < VROWS * 64; e += 256) {
+        const int d = e / 64, key = e % 64, s = tile * 64 + key;
+        T v = from_f32<T>(0.0f);
+        if (s < S && d < HD) v = qkv[(size_t)(f * S + s) * ld + 2 * Hv + head * HD + d];
+        vp[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ vision
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* pix, T* out, int F, int image, int patch, int kp) {
+    const int side = image / patch;
+    const int prow = blockIdx.x;                          // f*side*side + py*side + px
+    const int f = prow / (side * side), pp = prow % (side * side), py = pp / side, px = pp % side;
+    const int kreal = 3 * patch * patch;
+    for (int k = threadIdx.x; k < kp; k += 256) {
+        float v = 0.0f;
+        if (k < kreal) {
+            const int c = k / (patch * patch), rem = k % (patch * patch), ky = rem / patch, kx = rem % patch;
+            v = pix[(((size_t)f * 3 + c) * image + (py * patch + ky)) * image + px * patch + kx];
+        }
+        out[(size_t)prow * kp + k] = from_f32<T>(v);
+    }
+}
+
+// bilinear pooling, ATen upsample_bilinear2d order: w0y*(w0x*a + w1x*b) + w1y*(w0x*c + w1x*d)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_kernel(const T* in, T* out, const int* tap_idx, const float* tap_w, int side, int oside, int C) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int o = blockIdx.x;                              // f*oside*oside + oy*oside + ox
+    const int f = o / (oside * oside), oo = o % (oside * oside), oy = oo / oside, ox = oo % oside;
+    const int y0 = tap_idx[2 * oy], y1 = tap_idx[2 * oy + 1], x0 = tap_idx[2 * ox], x1 = tap_idx[2 * ox + 1];
+    const float wy0 = tap_w[2 * oy], wy1 = tap_w[2 * oy + 1], wx0 = tap_w[2 * ox], wx1 = tap_w[2 * ox + 1];
+    const T* base = in + (size_t)f * side * side * C;
+    const T* a = base + (size_t)(y0 * side + x0) * C;
+    const T* b = base + (size_t)(y0 * side + x1) * C;
+    const T* c = base + (size_t)(y1 * side + x0) * C;
+    const T* d = base + (size_t)(y1 * side + x1) * C;
+    T* orow = out + (size_t)o * C;
+    for (int ci = threadIdx.x; ci < C / EPC; ci += 256) {
+        float fa[EPC], fb[EPC], fc[EPC], fd[EPC], r[EPC];
+        chunk_to_f32<T>(*(const uint4*)(a + (size_t)ci * EPC), fa);
+        chunk_to_f32<T>(*(const uint4*)(b + (size_t)ci * EPC), fb);
+        chunk_to_f32<T>(*(const uint4*)(c + (size_t)ci * EPC), fc);
+        chunk_to_f32<T>(*(const uint4*)(d + (size_t)ci * EPC), fd);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) r[e] = wy0 * (wx0 * fa[e] + wx1 * fb[e]) + wy1 * (wx0 * fc[e] + wx1 * fd[e]);
+        *(uint4*)(orow + (size_t)ci * EPC) = f32_to_chunk<T>(r);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int* src, const T* embed, const T* feats, T* out, int n) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int row = blockIdx.x;
+    const int sidx = src[row];
+    const T* s = sidx >= 0 ? embed + (size_t)sidx * n : feats + (size_t)(-(sidx + 1)) * n;
+    T* o = out + (size_t)row * n;
+    for (int ci = threadIdx.x; ci < n / EPC; ci += 256) *(uint4*)(o + (size_t)ci * EPC) = *(const uint4*)(s + (size_t)ci * EPC);
+}
+
+// ----------------------------------------------------------------------------------------- weights
+SVLN_DEV int64_t map_row(int64_t r, RowMap m) { return (r / m.blk) * (int64_t)m.blk * m.nint + (int64_t)m.phase * m.blk + r % m.blk; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void synth_kernel(T* dst, int dst_ld, int64_t rows, int cols, RowMap m, uint64_t seed_t, float step,
+                                                    float base) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        // weights are defined as bf16 values (like the real checkpoint); the fp32 engine stores them widened
+        dst[map_row(r, m) * dst_ld + c] = from_f32<T>(to_f32((bf16)synth_value(seed_t, (uint64_t)i, step, base)));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(T* dst, int dst_ld, int64_t rows, int cols, RowMap m, const void* src, int src_is_f32) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = src_is_f32 ? ((const float*)src)[i] : to_f32(((const bf16*)src)[i]);
+        dst[map_row(r, m) * dst_ld + c] = from_f32<T>(v);
+    }
+}
+
+template <typename T> __global__ void to_f32_kernel(const T* s, float* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = to_f32(s[i]);
+}
+template <typename T> __global__ void from_f32_kernel(const float* s, T* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = from_f32<T>(s[i]);
+}
+
+int grid_for(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (T*)y, rows, n, eps);
+}
+template <typename T> void launch_layernorm(hipStream_t s, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (const T*)b, (T*)y, rows, n, eps);
+}
+template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a) {
+    hipLaunchKernelGGL((rope_kv_kernel<T>), dim3(a.T, a.nq + 2 * a.nkv), dim3(64), 0, s, a);
+}
+template <typename T> void launch_vit_kv_pack(hipStream_t s, const void* qkv, int ld, void* Kpool, void* Vpool, int F, int S, int heads,
+                                             int head_dim) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int hdc = (((head_dim + EPC - 1) / EPC) + 1) & ~1;
+    const int vrows = ((head_dim + 31) / 32) * 32;
+    hipLaunchKernelGGL((vit_kv_pack_kernel<T>), dim3((S + 63) / 64, F * heads), dim3(256), 0, s, (const T*)qkv, ld, (T*)Kpool, (T*)Vpool, F, S,
+                       heads, head_dim, hdc * EPC, vrows);
+}
+template <typename T> void launch_patchify(hipStream_t s, const float* pix, void* out, int F, int image, int patch, int kp) {
+    const int side = image / patch;
+    hipLaunchKernelGGL((patchify_kernel<T>), dim3(F * side * side), dim3(256), 0, s, pix, (T*)out, F, image, patch, kp);
+}
+template <typename T> void launch_pool(hipStream_t s, const void* in, void* out, const int* tap_idx, const float* tap_w, int F, int side,
+                                       int out_side, int C) {
+    hipLaunchKernelGGL((pool_kernel<T>), dim3(F * out_side * out_side), dim3(256), 0, s, (const T*)in, (T*)out, tap_idx, tap_w, side, out_side, C);
+}
+template <typename T> void launch_gather_rows(hipStream_t s, const int* src, const void* embed, const void* feats, void* out, int rows, int n) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(rows), dim3(256), 0, s, src, (const T*)embed, (const T*)feats, (T*)out, n);
+}
+template <typename T> void launch_synth(hipStream_t s, void* dst, int dst_ld, int64_t rows, int cols, RowMap m, uint64_t seed_t,
+                                        float half_width, float base) {
+    const float step = half_width / 8388608.0f;
+    hipLaunchKernelGGL((synth_kernel<T>), dim3(grid_for(rows * cols)), dim3(256), 0, s, (T*)dst, dst_ld, rows, cols, m, seed_t, step, base);
+}
+template <typename T> void launch_convert(hipStream_t s, void* dst, int dst_ld, int64_t rows, int cols, RowMap m, const void* src, int src_is_f32) {
+    hipLaunchKernelGGL((convert_kernel<T>), dim3(grid_for(rows * cols)), dim3(256), 0, s, (T*)dst, dst_ld, rows, cols, m, src, src_is_f32);
+}
+template <typename T> void launch_to_f32(hipStream_t s, const void* src, float* dst, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((to_f32_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)src, dst, n);
+}
+template <typename T> void launch_from_f32(hipStream_t s, const float* src, void* dst, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((from_f32_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, src, (T*)dst, n);
+}
+
+#define SVLN_INST(T)                                                                                                              \
+    template void launch_rmsnorm<T>(hipStream_t, const void*, const void*, void*, int, int, float);                              \
+    template void launch_layernorm<T>(hipStream_t, const void*, const void*, const void*, void*, int, int, float);               \
+    template void launch_rope_kv<T>(hipStream_t, const RopeKvArgs&);                                                              \
+    template void launch_vit_kv_pack<T>(hipStream_t, const void*, int, void*, void*, int, int, int, int);                         \
+    template void launch_patchify<T>(hipStream_t, const float*, void*, int, int, int, int);                                       \
+    template void launch_pool<T>(hipStream_t, const void*, void*, const int*, const float*, int, int, int, int);                  \
+    template void launch_gather_rows<T>(hipStream_t, const int*, const void*, const void*, void*, int, int);                      \
+    template void launch_synth<T>(hipStream_t, void*, int, int64_t, int, RowMap, uint64_t, float, float);                          \
+    template void launch_convert<T>(hipStream_t, void*, int, int64_t, int, RowMap, const void*, int);                              \
+    template void launch_to_f32<T>(hipStream_t, const void*, float*, int64_t);                                                    \
+    template void launch_from_f32<T>(hipStream_t, const float*, void*, int64_t);
+SVLN_INST(bf16)
+SVLN_INST(float)
+
+}  // namespace svln

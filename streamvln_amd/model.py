@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's operator surface for the streaming path.
+
+`StreamVLNForCausalLM` here keeps the names, argument meaning and error behaviour of
+streamvln/model/stream_video_vln.py (`generate`, `reset`, `reset_for_env`, `get_vision_tower`,
+`get_model`, `.model.num_history`) so `VLNEvaluator.step` / the Habitat eval loop
+(streamvln/streamvln_agent.py:169-258, streamvln/streamvln_eval.py:290-350) call it unchanged.
+All arithmetic happens in the HIP engine behind include/streamvln_hip.h; PyTorch is used only
+for the caller's tensors (device memory in / token ids out).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Dict, Iterable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import CONFIGS, StreamVLNConfig
+from .weights import tensor_seed, tensor_specs
+
+
+def _check(rc):
+    _lib.check(rc)
+
+
+class SigLipImageProcessor:
+    """llava/model/multimodal_encoder/siglip_encoder.py:34-67: PIL bicubic resize to 384x384
+    (aspect not preserved), x/255, (x-0.5)/0.5, channels first.  Stays on the host: PIL's bicubic
+    is only exactly reproducible on the CPU."""
+
+    def __init__(self, size=(384, 384)):
+        self.image_mean, self.image_std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)
+        self.size = size
+        self.rescale_factor = 1 / 255
+        self.crop_size = {"height": size[0], "width": size[1]}
+
+    def preprocess_array(self, rgb) -> torch.Tensor:
+        from PIL import Image
+        img = rgb if isinstance(rgb, Image.Image) else Image.fromarray(np.asarray(rgb, dtype=np.uint8))
+        img = img.convert("RGB").resize((self.size[1], self.size[0]), resample=Image.BICUBIC)
+        a = (np.asarray(img).astype(np.float64) * self.rescale_factor).astype(np.float32)
+        a = (a - np.float32(0.5)) / np.float32(0.5)
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+    def preprocess(self, images, return_tensors="pt"):
+        from PIL import Image
+        if isinstance(images, Image.Image) or (isinstance(images, np.ndarray) and images.ndim == 3):
+            images = [images]
+        vals = [self.preprocess_array(im) for im in images]
+        if return_tensors == "pt":
+            return {"pixel_values": torch.stack(vals)}
+        return {"pixel_values": [v.numpy() for v in vals]}
+
+
+class _VisionTower:
+    def __init__(self, cfg: StreamVLNConfig):
+        self.config = SimpleNamespace(hidden_size=cfg.v_hidden, image_size=cfg.v_image, patch_size=cfg.v_patch)
+        self.image_processor = SigLipImageProcessor((cfg.v_image, cfg.v_image))
+        self.is_loaded = True
+
+    @property
+    def num_patches_per_side(self):
+        return self.config.image_size // self.config.patch_size
+
+    @property
+    def num_patches(self):
+        return self.num_patches_per_side ** 2
+
+    @property
+    def hidden_size(self):
+        return self.config.hidden_size
+
+
+class KVHandle:
+    """Opaque `past_key_values` handle: the KV pages live in the engine, keyed by env."""
+
+    def __init__(self, env_id: int, epoch: int, length: int):
+        self.env_id, self.epoch, self.length = env_id, epoch, length
+
+    def get_seq_length(self):
+        return self.length
+
+    def __len__(self):
+        return self.length
+
+
+class GenerateOutput(dict):
+    """`return_dict_in_generate=True` result: `.sequences` (new tokens only, EOS included) and
+    `.past_key_values` (streamvln_eval.py:334-335)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class StreamVLNForCausalLM:
+    def __init__(self, config: StreamVLNConfig, dtype: torch.dtype = torch.bfloat16, device: int = 0, max_envs: int = 1,
+                 max_frames: int = 9, max_positions: Optional[int] = None):
+        lib = _lib.load()
+        self.cfg = config
+        self.dtype = dtype
+        self.device_index = device
+        c = _lib.SvlnConfig(
+            v_hidden=config.v_hidden, v_inter=config.v_inter, v_heads=config.v_heads, v_layers=config.v_layers,
+            v_patch=config.v_patch, v_image=config.v_image, v_eps=config.v_eps,
+            hidden=config.hidden, layers=config.layers, q_heads=config.q_heads, kv_heads=config.kv_heads,
+            head_dim=config.head_dim, inter=config.inter, vocab=config.vocab, rope_theta=config.rope_theta,
+            rms_eps=config.rms_eps, max_positions=max_positions or config.max_positions, max_envs=max_envs,
+            max_frames=max_frames, dtype=_lib.SVLN_F32 if dtype == torch.float32 else _lib.SVLN_BF16)
+        h = C.c_void_p()
+        _check(lib.svln_create(C.byref(c), device, C.byref(h)))
+        self._lib, self._h = lib, h
+        self.max_envs, self.max_frames = max_envs, max_frames
+        self._tower = _VisionTower(config)
+        # `.model` = StreamVLNModel in the reference; callers set `.model.num_history` (streamvln_eval.py:531)
+        self.model = SimpleNamespace(num_history=None, get_vision_tower=lambda: self._tower)
+        self.config = SimpleNamespace(mm_spatial_pool_mode="bilinear", hidden_size=config.hidden, vocab_size=config.vocab)
+        self.generation_config = SimpleNamespace(eos_token_id=[151645, 151643])   # Qwen2-7B-Instruct <|im_end|>, <|endoftext|>
+        self.reset(max_envs)
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config, seed: Optional[int] = None, **kw):
+        if isinstance(config, str):
+            config = CONFIGS[config]
+        m = cls(config, **kw)
+        if seed is not None:
+            m.load_synthetic(seed)
+        return m
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, torch_dtype=torch.bfloat16, attn_implementation=None, low_cpu_mem_usage=False,
+                        device: int = 0, **kw):
+        """Checkpoint ingestion (HF safetensors layout).  No checkpoint exists offline."""
+        import glob
+        import os
+        files = sorted(glob.glob(os.path.join(str(path), "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        from safetensors import safe_open
+        from .config import TRUE
+        m = cls(config if isinstance(config, StreamVLNConfig) else TRUE, dtype=torch_dtype, device=device, **kw)
+        for f in files:
+            with safe_open(f, framework="pt") as sf:
+                for name in sf.keys():
+                    if name in m.tensor_names():
+                        m.set_tensor(name, sf.get_tensor(name))
+        m.check_weights()
+        return m
+
+    def tensor_names(self):
+        return {s.name for s in tensor_specs(self.cfg)}
+
+    def load_synthetic(self, seed: int):
+        """Seeded random-init weights generated on the device (streamvln_amd/weights.py)."""
+        for s in tensor_specs(self.cfg):
+            _check(self._lib.svln_synth_tensor(self._h, s.name.encode(), tensor_seed(seed, s.name), s.half_width, s.base))
+        self.check_weights()
+        return self
+
+    def set_tensor(self, name: str, value):
+        if isinstance(value, torch.Tensor):
+            t = value.detach()
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                t = t.float()
+            t = t.contiguous()
+            dt = _lib.SVLN_F32 if t.dtype == torch.float32 else _lib.SVLN_BF16
+            if t.is_cuda:
+                torch.cuda.synchronize()
+            _check(self._lib.svln_set_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, t.numel(), int(t.is_cuda)))
+        else:
+            a = np.ascontiguousarray(value, dtype=np.float32)
+            _check(self._lib.svln_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), _lib.SVLN_F32, a.size, 0))
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        for k, v in sd.items():
+            self.set_tensor(k, v)
+        self.check_weights()
+        return self
+
+    def check_weights(self):
+        _check(self._lib.svln_weights_ready(self._h))
+
+    def get_tensor(self, name: str) -> np.ndarray:
+        spec = {s.name: s for s in tensor_specs(self.cfg)}[name]
+        out = np.empty(spec.numel, dtype=np.float32)
+        _check(self._lib.svln_get_tensor_f32(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out.reshape(spec.shape)
+
+    # ---- nn.Module-flavoured no-ops the harness calls (streamvln_eval.py:531-539) -----------------
+    def requires_grad_(self, flag=False):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self._tower
+
+    @property
+    def device(self):
+        return torch.device("cuda", self.device_index)
+
+    # ---- session state (stream_video_vln.py:473-479) ----------------------------------------------
+    def reset(self, env_num: int):
+        if env_num > self.max_envs:
+            raise ValueError(f"env_num {env_num} exceeds the engine's max_envs {self.max_envs}")
+        self.curr_t = [0] * env_num
+        self._epoch = [0] * env_num
+        for i in range(env_num):
+            _check(self._lib.svln_reset_env(self._h, i))
+
+    def reset_for_env(self, env_idx: int):
+        self.curr_t[env_idx] = 0
+        self._epoch[env_idx] += 1
+        _check(self._lib.svln_reset_env(self._h, env_idx))
+
+    # ---- the call (stream_video_vln.py:353-407) -------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, image_sizes=None, depths=None, poses=None, intrinsics=None, task_ids=None,
+                 **kwargs):
+        kwargs.pop("position_ids", None)
+        kwargs.pop("attention_mask", None)
+        time_ids = kwargs.pop("time_ids", None)
+        kwargs.pop("task_type", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        env_id = kwargs.pop("env_id", None)
+        past = kwargs.pop("past_key_values", None)
+        max_new = int(kwargs.pop("max_new_tokens", 10000))
+        eos = kwargs.pop("eos_token_ids", None)
+        if kwargs.get("do_sample", False) or kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("only greedy decoding (do_sample=False, num_beams=1) is on the path")
+        if eos is None:
+            eos = self.generation_config.eos_token_id
+        eos = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+        if images is None:
+            raise NotImplementedError("text-only turns are not part of the streaming path")
+        if env_id is None or not (0 <= env_id < len(self.curr_t)):
+            raise IndexError(f"env_id {env_id} out of range")
+
+        ids = torch.as_tensor(inputs).reshape(-1).to("cpu", torch.int64)
+        if ids.numel() == 1:
+            raise NotImplementedError("single-token `inputs` bypasses the multimodal path in the reference "
+                                      "(stream_video_vln.py:149)")
+        B, V = images.shape[0], images.shape[1]
+        if B != 1:
+            raise NotImplementedError("one env per generate call (reference harnesses run batch 1)")
+        n_memory = 0
+        if V != 1:                                            # encode_rgbd, stream_video_vln.py:111-130
+            start_idx = time_ids[0][0] if (time_ids is not None and time_ids[0] is not None) else 0
+            if start_idx != 0:
+                if self.model.num_history is None:
+                    raise TypeError("model.num_history must be set before a <memory> turn")
+                n_memory = int(self.model.num_history)
+        pix = images[0].to(torch.float32).contiguous()
+        on_dev = int(pix.is_cuda)
+        if on_dev:
+            torch.cuda.synchronize(pix.device)
+        _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+
+        if past is None:
+            _check(self._lib.svln_kv_reset(self._h, env_id))
+        else:
+            if not isinstance(past, KVHandle) or past.env_id != env_id or past.epoch != self._epoch[env_id]:
+                raise ValueError("past_key_values does not belong to this env's current window")
+        if self.curr_t[env_id] == 0:                          # stream_video_vln.py:397-400
+            ne, kl = C.c_int32(), C.c_int32()
+            _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+            if ne.value != 0:
+                _check(self._lib.svln_reset_env(self._h, env_id))
+        self.curr_t[env_id] += 1
+
+        ids_np = np.ascontiguousarray(ids.numpy())
+        _check(self._lib.svln_append_turn(self._h, env_id, ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
+        cap = min(max_new, self.cfg.max_positions)
+        out = np.zeros(cap, dtype=np.int64)
+        n_out = C.c_int32()
+        eos_np = np.asarray(eos, dtype=np.int64)
+        _check(self._lib.svln_generate(self._h, env_id, max_new, eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
+                                       out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n_out)))
+        ne, kl = C.c_int32(), C.c_int32()
+        _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+        dev = inputs.device if isinstance(inputs, torch.Tensor) else "cpu"
+        seq = torch.from_numpy(out[: n_out.value].copy()).unsqueeze(0).to(dev)
+        return GenerateOutput(sequences=seq, past_key_values=KVHandle(env_id, self._epoch[env_id], kl.value))
+
+    # ---- parity taps (tests) / perf helpers (bench) ---------------------------------------------------
+    def last_hidden(self) -> np.ndarray:
+        buf = np.empty((64, self.cfg.hidden), dtype=np.float32)
+        n = C.c_int32()
+        _check(self._lib.svln_get_hidden(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), 64, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def env_state(self, env_id=0):
+        ne, kl = C.c_int32(), C.c_int32()
+        _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+        return ne.value, kl.value
+
+    def get_embeds(self, env_id, start, n) -> np.ndarray:
+        out = np.empty((n, self.cfg.hidden), dtype=np.float32)
+        _check(self._lib.svln_get_embeds(self._h, env_id, start, n, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_decode_graph(self, enable: bool):
+        _check(self._lib.svln_set_decode_graph(self._h, int(enable)))
+
+    def sync(self):
+        _check(self._lib.svln_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.svln_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

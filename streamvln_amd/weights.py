@@ -12,9 +12,11 @@ Every element is a pure function of (global seed, tensor name, flat index):
     v  = (float32(m) - 2^23) * (a / 2^23)          uniform in [-a, a), exact in fp32
     w  = base + v                                  base = 1 for norm gains, else 0
 
-The identical arithmetic runs on the device (`csrc/fill.hip`), in numpy here, so the HIP
-engine, the CPU oracle and the imported reference all see bit-identical weights without
-15 GB crossing PCIe.  bf16 storage rounds `w` to nearest-even.
+    W  = bf16(w)                                   round-to-nearest-even: weights are bf16 values
+
+The identical arithmetic runs on the device (`csrc/misc.hip` synth_kernel), in numpy here, so the
+HIP engine (bf16 or fp32 parity mode), the CPU oracle and the imported reference all see
+bit-identical weights without 15 GB crossing PCIe.
 """
 from __future__ import annotations
 
@@ -140,14 +142,14 @@ def tensor_specs(cfg: StreamVLNConfig) -> List[TensorSpec]:
     return s
 
 
-def synth_tensor(spec: TensorSpec, seed: int, bf16_round: bool) -> np.ndarray:
+def synth_tensor(spec: TensorSpec, seed: int, bf16_round: bool = True) -> np.ndarray:
     v = synth_flat(tensor_seed(seed, spec.name), 0, spec.numel, spec.half_width, spec.base)
     if bf16_round:
         v = round_to_bf16(v)
     return v.reshape(spec.shape)
 
 
-def synth_state_dict(cfg: StreamVLNConfig, seed: int, bf16_round: bool,
+def synth_state_dict(cfg: StreamVLNConfig, seed: int, bf16_round: bool = True,
                      only: Iterable[str] | None = None) -> Dict[str, np.ndarray]:
     """All canonical tensors as fp32 numpy arrays (bf16-rounded values when `bf16_round`)."""
     want = None if only is None else set(only)

@@ -1,0 +1,132 @@
+"""CPU: host-side logic (agent turn protocol, splice descriptors, weights generator, image processor, C ABI surface)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from streamvln_amd import _lib, weights as W
+from streamvln_amd.agent import StreamingAgent, parse_actions
+from streamvln_amd.config import TINY, TRUE, IMAGE_TOKEN_INDEX, MEMORY_TOKEN_INDEX
+from streamvln_amd.model import SigLipImageProcessor
+from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+from oracle import streamvln_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeModel:
+    """records generate calls; returns 2 tokens per turn"""
+
+    def __init__(self):
+        self.calls, self.resets = [], 0
+
+    def reset_for_env(self, i):
+        self.resets += 1
+
+    def generate(self, **kw):
+        self.calls.append(kw)
+        n = len(self.calls)
+        out = type("O", (), {})()
+        out.sequences = torch.tensor([[100 + n, 200 + n]])
+        out.past_key_values = ("kv", n)
+        return out
+
+
+def _agent(model, **kw):
+    return StreamingAgent(model, SyntheticPromptEncoder(TINY, first_len=20, memory_len=26, later_len=8),
+                          preprocess=lambda rgb: torch.zeros(3, 4, 4) + float(rgb), **kw)
+
+
+def test_turn_protocol_matches_reference_loop():
+    """streamvln_eval.py:290-350 with num_frames 8, num_future_steps 4, num_history 2"""
+    m = FakeModel()
+    ag = _agent(m, num_frames=8, num_future_steps=4, num_history=2)
+    for step in range(20):
+        ag.act(step)
+    c = m.calls
+    assert [k["time_ids"][0][0] for k in c] == [0, 0, 8, 8, 16]                 # window starts
+    assert [k["images"].shape[1] for k in c] == [1, 1, 3, 1, 3]                  # 2 history frames + current at restarts
+    assert [k["past_key_values"] for k in c] == [None, ("kv", 1), None, ("kv", 3), None]
+    # first turn: new prompt only; later turn: previous output ids prepended (streamvln_eval.py:305-306)
+    assert c[0]["inputs"].shape[1] == 20 and c[1]["inputs"].shape[1] == 2 + 8
+    assert c[1]["inputs"][0, :2].tolist() == [101, 201]
+    assert c[2]["inputs"].shape[1] == 26 and (c[2]["inputs"] == MEMORY_TOKEN_INDEX).sum() == 1
+    assert (c[0]["inputs"] == MEMORY_TOKEN_INDEX).sum() == 0 and (c[0]["inputs"] == IMAGE_TOKEN_INDEX).sum() == 1
+    # history frames = rgb_list[0 : t0 : t0 // num_history]  -> steps 0 and 4 at t0 = 8; 0 and 8 at t0 = 16
+    assert c[2]["images"][0, :, 0, 0, 0].tolist() == [0.0, 4.0, 8.0]
+    assert c[4]["images"][0, :, 0, 0, 0].tolist() == [0.0, 8.0, 16.0]
+    assert m.resets == 1 + 2                                                       # constructor + two window resets
+    assert c[0]["do_sample"] is False and c[0]["num_beams"] == 1 and c[0]["use_cache"] is True
+
+
+def test_step_flavour_window_reset():
+    """streamvln_agent.py:169-258: run_model=False steps only record; reset when (step_id+1) % num_frames == 0"""
+    m = FakeModel()
+    ag = _agent(m, num_frames=4, num_future_steps=4, num_history=2)
+    acts, _, _ = ag.step(0, 1, "go", run_model=True)
+    assert acts == [1, 1, 1, 1] and len(m.calls) == 1
+    for s in (1, 2, 3):
+        ag.step_id = s
+        assert ag.step(0, 1, "go", run_model=False) == (None, 0, None)
+    assert ag.output_ids is None and ag.past_key_values is None and ag.time_ids == []
+    ag.step_id = 4
+    ag.step(0, 2, "go", run_model=True)
+    assert m.calls[1]["images"].shape[1] == 3 and m.calls[1]["time_ids"] == [[4]]
+
+
+def test_parse_actions():
+    assert parse_actions("↑↑←→STOP") == [1, 1, 2, 3, 0]
+    assert parse_actions("nothing here") == []
+
+
+def test_weight_generator_is_pure_and_matches_spec():
+    assert W.fnv1a64("") == 0xCBF29CE484222325 and W.fnv1a64("a") == 0xAF63DC4C8601EC8C
+    spec = [s for s in W.tensor_specs(TINY) if s.name == "model.layers.1.mlp.up_proj.weight"][0]
+    a = W.synth_tensor(spec, 1234)
+    seed_t = W.tensor_seed(1234, spec.name)
+    part = W.round_to_bf16(W.synth_flat(seed_t, 1000, 50, spec.half_width, spec.base))
+    assert np.array_equal(a.reshape(-1)[1000:1050], part)
+    # scalar re-derivation of one element
+    idx = 12345
+    z = W.splitmix64_int(seed_t + idx * 0x9E3779B97F4A7C15)
+    v = (np.float32(z >> 40) - np.float32(8388608.0)) * (np.float32(spec.half_width) / np.float32(8388608.0))
+    assert a.reshape(-1)[idx] == W.round_to_bf16(np.array([v], dtype=np.float32))[0]
+    assert np.abs(a).max() <= spec.half_width * 1.004 and abs(float(a.mean())) < 0.01      # bf16 rounding can exceed a by 2^-9
+    assert np.array_equal(W.round_to_bf16(a), a)                                  # values are bf16-representable
+    n_true = sum(s.numel for s in W.tensor_specs(TRUE))
+    assert 7.9e9 < n_true < 8.1e9                                                  # 7.07 B LLM + 0.55 B embed + ViT + projector
+    gains = [s for s in W.tensor_specs(TINY) if s.name.endswith("layernorm.weight")]
+    assert all(s.base == 1.0 for s in gains)
+
+
+def test_image_processor_equals_oracle_preprocess():
+    frame = synthetic_frame(0, 3)
+    proc = SigLipImageProcessor()
+    a = proc.preprocess_array(frame).numpy()
+    assert np.array_equal(a, O.siglip_preprocess(frame))
+    from PIL import Image
+    pv = proc.preprocess(images=Image.fromarray(frame), return_tensors="pt")["pixel_values"][0]
+    assert np.array_equal(pv.numpy(), a) and proc.crop_size == {"height": 384, "width": 384}
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "streamvln_hip.h")).read()
+    declared = set(re.findall(r"\b(svln_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (svln_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_engine_fails_loudly_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from streamvln_amd.model import StreamVLNForCausalLM
+    with pytest.raises(_lib.SvlnError):
+        StreamVLNForCausalLM(TINY)

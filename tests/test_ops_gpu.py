@@ -1,0 +1,256 @@
+"""Op-level parity: every HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs, in both engine dtypes (fp32 parity mode: tight; bf16 shipping mode: bf16-rounding bound)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from streamvln_amd import _lib
+from streamvln_amd.config import TINY, TRUE1
+from streamvln_amd.model import StreamVLNForCausalLM
+from streamvln_amd import weights as W
+from oracle import streamvln_oracle as O
+from util import assert_close, ptr, q, rnd
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+_engines = {}
+
+
+def engine(cfg, dtype):
+    key = (cfg.name, dtype)
+    if key not in _engines:
+        _engines[key] = StreamVLNForCausalLM(cfg, dtype=dtype, max_envs=1, max_frames=3, max_positions=2048)
+    return _engines[key]
+
+
+def chk(rc):
+    _lib.check(rc)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,epi,bias,res", [
+    (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
+    (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
+    (729, 4304, 1152, _lib.EPI_GELU_TANH, True, False),  # ViT fc1: N not a multiple of 128
+    (130, 1152, 4304, _lib.EPI_NONE, True, True),        # ViT fc2: K not a multiple of the stage
+    (64, 256, 592, _lib.EPI_GELU_ERF, True, False),      # patch-embed K
+    (1, 128, 64, _lib.EPI_NONE, False, False),           # degenerate
+])
+def test_gemm(dtype, M, N, K, epi, bias, res):
+    m = engine(TINY, dtype)
+    A, Wt = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1.0 / math.sqrt(K)), dtype)
+    b = q(rnd((N,), 3, 0.1), dtype) if bias else None
+    r = q(rnd((M, N), 4), dtype) if res else None
+    exp = A @ Wt.t()
+    if b is not None:
+        exp = exp + b
+    if epi == _lib.EPI_GELU_TANH:
+        exp = O.gelu_tanh(exp)
+    if epi == _lib.EPI_GELU_ERF:
+        exp = O.gelu_erf(exp)
+    if r is not None:
+        exp = exp + r
+    dA, dW = A.to(dtype).cuda(), Wt.to(dtype).cuda()
+    db = b.to(dtype).cuda() if bias else None
+    dr = r.to(dtype).cuda() if res else None
+    out = torch.zeros((M, N), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), N, ptr(db), ptr(dr), N, 0, M, N, K, epi))
+    assert_close(out, exp, dtype, f"gemm {M}x{N}x{K} epi{epi}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_swiglu_and_posmod(dtype):
+    m = engine(TINY, dtype)
+    M, I, K = 150, 256, 512
+    A = q(rnd((M, K), 5), dtype)
+    gate, up = q(rnd((I, K), 6, 0.08), dtype), q(rnd((I, K), 7, 0.08), dtype)
+    packed = torch.zeros((2 * I, K))
+    for j in range(I):                                   # 32-row blocks: [gate 32 | up 32]
+        packed[(j // 32) * 64 + j % 32] = gate[j]
+        packed[(j // 32) * 64 + 32 + j % 32] = up[j]
+    exp = O.silu(A @ gate.t()) * (A @ up.t())
+    out = torch.zeros((M, I), dtype=dtype, device="cuda")
+    dA, dW = A.to(dtype).cuda(), packed.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU))
+    assert_close(out, exp, dtype, "gemm swiglu")
+    # residual with row modulo (position embedding add of the patch GEMM)
+    S, N = 50, 128
+    Wt, pos, b = q(rnd((N, K), 8, 0.05), dtype), q(rnd((S, N), 9), dtype), q(rnd((N,), 10), dtype)
+    exp = A @ Wt.t() + b + pos[torch.arange(M) % S]
+    out = torch.zeros((M, N), dtype=dtype, device="cuda")
+    dW, dp, db = Wt.to(dtype).cuda(), pos.to(dtype).cuda(), b.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), N, ptr(db), ptr(dp), N, S, M, N, K, _lib.EPI_NONE))
+    assert_close(out, exp, dtype, "gemm res_mod")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,K,norm,bias,res", [(4608, 3584, True, True, False), (3584, 18944, False, False, True),
+                                               (515, 512, True, False, True), (7, 64, False, True, False)])
+def test_gemv(dtype, N, K, norm, bias, res):
+    m = engine(TINY, dtype)
+    Wt, x = q(rnd((N, K), 11, 1.0 / math.sqrt(K)), dtype), q(rnd((K,), 12), dtype)
+    g = q(1 + rnd((K,), 13, 0.1), dtype) if norm else None
+    b = q(rnd((N,), 14, 0.1), dtype) if bias else None
+    r = q(rnd((N,), 15), dtype) if res else None
+    xe = O.rms_norm(x, g, 1e-6) if norm else x
+    exp = Wt @ xe
+    if b is not None:
+        exp = exp + b
+    if r is not None:
+        exp = exp + r
+    d = lambda t: t.to(dtype).cuda() if t is not None else None
+    dW, dx, dg, db, dr = d(Wt), d(x), d(g), d(b), d(r)
+    y = torch.zeros((N,), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv(m._h, ptr(dW), K, ptr(dx), ptr(dg), 1e-6, ptr(db), ptr(dr), ptr(y), N, K, _lib.EPI_NONE, None))
+    assert_close(y, exp, dtype, f"gemv {N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemv_swiglu_and_argmax(dtype):
+    m = engine(TINY, dtype)
+    I, K = 1024, 512
+    x = q(rnd((K,), 16), dtype)
+    g = q(1 + rnd((K,), 17, 0.1), dtype)
+    gate, up = q(rnd((I, K), 18, 0.08), dtype), q(rnd((I, K), 19, 0.08), dtype)
+    packed = torch.zeros((2 * I, K))
+    idx = torch.arange(I)
+    packed[(idx // 32) * 64 + idx % 32] = gate
+    packed[(idx // 32) * 64 + 32 + idx % 32] = up
+    xe = O.rms_norm(x, g, 1e-6)
+    exp = O.silu(gate @ xe) * (up @ xe)
+    y = torch.zeros((I,), dtype=dtype, device="cuda")
+    dW, dx, dg = packed.to(dtype).cuda(), x.to(dtype).cuda(), g.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv(m._h, ptr(dW), K, ptr(dx), ptr(dg), 1e-6, None, None, ptr(y), 2 * I, K, _lib.EPI_SWIGLU, None))
+    assert_close(y, exp, dtype, "gemv swiglu")
+    # arg-max with an exact tie between two rows: the lowest index must win (torch.argmax on CPU)
+    V = 5000
+    Wv = q(rnd((V, K), 20, 0.05), dtype)
+    Wv[77] = q(x * 0.02, dtype)
+    Wv[4321] = Wv[77]
+    logits = Wv @ x
+    assert int(torch.argmax(logits)) == 77 and float(logits[77]) == float(logits[4321])
+    tok = C.c_int32(-1)
+    dWv = Wv.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv(m._h, ptr(dWv), K, ptr(dx), None, 1e-6, None, None, None, V, K, _lib.EPI_ARGMAX, C.byref(tok)))
+    assert tok.value == 77, tok.value
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norms(dtype):
+    m = engine(TINY, dtype)
+    for rows, n in [(213, 3584), (729, 1152), (5, 144)]:
+        x = q(rnd((rows, n), 21, 3.0) + 0.5, dtype)
+        g, b = q(1 + rnd((n,), 22, 0.1), dtype), q(rnd((n,), 23, 0.1), dtype)
+        dx, dg, db = x.to(dtype).cuda(), g.to(dtype).cuda(), b.to(dtype).cuda()
+        y = torch.zeros_like(dx)
+        torch.cuda.synchronize()
+        chk(m._lib.svln_op_rmsnorm(m._h, ptr(dx), ptr(dg), ptr(y), rows, n, 1e-6))
+        assert_close(y, O.rms_norm(x, g, 1e-6), dtype, f"rmsnorm {rows}x{n}")
+        chk(m._lib.svln_op_layernorm(m._h, ptr(dx), ptr(dg), ptr(db), ptr(y), rows, n, 1e-6))
+        assert_close(y, O.layer_norm(x, g, b, 1e-6), dtype, f"layernorm {rows}x{n}")
+
+
+def _llm_attention_oracle(cfg, qkv_ctx, qkv_new, P):
+    nq, nkv, hd = cfg.q_heads, cfg.kv_heads, cfg.head_dim
+    allr = torch.cat([qkv_ctx, qkv_new], 0) if P > 0 else qkv_new
+    L = allr.shape[0]
+    pos = torch.arange(L)
+    cos, sin = O.rope_cos_sin(pos, hd, cfg.rope_theta)
+    qq = allr[:, : nq * hd].view(L, nq, hd)
+    kk = allr[:, nq * hd: (nq + nkv) * hd].view(L, nkv, hd)
+    vv = allr[:, (nq + nkv) * hd:].view(L, nkv, hd)
+    qq = qq * cos[:, None] + O.rotate_half(qq) * sin[:, None]
+    kk = kk * cos[:, None] + O.rotate_half(kk) * sin[:, None]
+    g = nq // nkv
+    T = qkv_new.shape[0]
+    qn = qq[P:].transpose(0, 1).reshape(nkv, g, T, hd)
+    s = torch.einsum("kgtd,ksd->kgts", qn, kk.transpose(0, 1)) * hd ** -0.5
+    mask = torch.arange(L)[None, :] > (P + torch.arange(T))[:, None]
+    s = s.masked_fill(mask[None, None], float("-inf"))
+    p = torch.softmax(s, -1)
+    o = torch.einsum("kgts,ksd->kgtd", p, vv.transpose(0, 1))
+    return o.reshape(nq, T, hd).transpose(0, 1).reshape(T, nq * hd)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg,T,P,nsplit", [(TINY, 212, 0, 1), (TINY, 37, 300, 1), (TINY, 1, 777, 8), (TINY, 3, 130, 8),
+                                            (TRUE1, 212, 800, 1), (TRUE1, 1, 1500, 8), (TRUE1, 376, 0, 1)])
+def test_attention_llm(dtype, cfg, T, P, nsplit):
+    """prefill (causal, bottom-right aligned over a cached context) and split-KV decode, incl. RoPE + paged KV append"""
+    m = engine(cfg, dtype)
+    ld = (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim
+    ctx = q(rnd((max(P, 1), ld), 31), dtype)
+    new = q(rnd((T, ld), 32), dtype)
+    exp = _llm_attention_oracle(cfg, ctx[:P], new, P)
+    dctx, dnew = ctx.to(dtype).cuda(), new.to(dtype).cuda()
+    out = torch.zeros((T, cfg.q_heads * cfg.head_dim), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_attention_llm(m._h, ptr(dnew), ld, T, P, ptr(dctx), P, ptr(out), cfg.q_heads * cfg.head_dim, nsplit))
+    assert_close(out, exp, dtype, f"attention llm T{T} P{P} split{nsplit}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg,F", [(TINY, 1), (TINY, 3), (TRUE1, 2)])
+def test_attention_vit(dtype, cfg, F):
+    m = engine(cfg, dtype)
+    S, Hv, nh, hd = cfg.v_tokens, cfg.v_hidden, cfg.v_heads, cfg.v_head_dim
+    qkv = q(rnd((F * S, 3 * Hv), 41), dtype)
+    x = qkv.view(F, S, 3, nh, hd)
+    qq, kk, vv = (x[:, :, i].transpose(1, 2) for i in range(3))
+    p = torch.softmax((qq @ kk.transpose(2, 3)) * hd ** -0.5, -1)
+    exp = (p @ vv).transpose(1, 2).reshape(F * S, Hv)
+    dq = qkv.to(dtype).cuda()
+    out = torch.zeros((F * S, Hv), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_attention_vit(m._h, ptr(dq), 3 * Hv, F, ptr(out), Hv))
+    assert_close(out, exp, dtype, f"attention vit F{F}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pool_and_patchify(dtype):
+    m = engine(TINY, dtype)
+    cfg = TINY
+    F = 2
+    feat = q(rnd((F, cfg.v_tokens, cfg.hidden), 51), dtype)
+    exp = O.pool_bilinear(cfg, feat)
+    ref = torch.nn.functional.interpolate(feat.view(F, 27, 27, -1).permute(0, 3, 1, 2), size=[14, 14], mode="bilinear")
+    assert torch.allclose(exp, ref.permute(0, 2, 3, 1).reshape(F, 196, -1), atol=1e-5)
+    din = feat.to(dtype).cuda()
+    out = torch.zeros((F, cfg.pool_tokens, cfg.hidden), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_pool(m._h, ptr(din), ptr(out), F))
+    assert_close(out, exp, dtype, "pool")
+    pix = rnd((F, 3, 384, 384), 52)
+    kp = 592
+    p_, side = cfg.v_patch, cfg.v_side
+    e = pix[:, :, : side * p_, : side * p_].reshape(F, 3, side, p_, side, p_).permute(0, 2, 4, 1, 3, 5).reshape(F * side * side, 588)
+    e = torch.cat([e, torch.zeros(e.shape[0], kp - 588)], 1)
+    dpix = pix.cuda()
+    out = torch.ones((F * side * side, kp), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_patchify(m._h, ptr(dpix), ptr(out), F))
+    assert_close(out, q(e, dtype), dtype, "patchify")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_synth_weights_bit_exact(dtype):
+    """device generator == numpy generator, element for element, incl. packed (qkv, gate/up) layouts"""
+    m = engine(TINY, dtype)
+    m.load_synthetic(99)
+    names = ["model.layers.1.mlp.gate_proj.weight", "model.layers.0.mlp.up_proj.weight", "model.layers.1.self_attn.k_proj.weight",
+             "model.layers.0.self_attn.v_proj.bias", "model.norm.weight", "lm_head.weight",
+             W.VT + "embeddings.patch_embedding.weight", W.VT + "encoder.layers.1.self_attn.v_proj.weight"]
+    specs = {s.name: s for s in W.tensor_specs(TINY)}
+    for n in names:
+        exp = W.synth_tensor(specs[n], 99)
+        got = m.get_tensor(n)
+        assert np.array_equal(got, exp), n

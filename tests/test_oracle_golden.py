@@ -1,0 +1,69 @@
+"""CPU: the oracle (fp32 restatement) reproduces the fixtures generated from the REFERENCE's own modules
+(oracle/make_golden.py).  tiny_episode is replayed in full; true1_episode (true dimensions) for its first turn."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import streamvln_oracle as O
+from scenarios import SCENARIOS, SEED, run_scenario
+from streamvln_amd import weights as W
+from streamvln_amd.synthetic import synthetic_frame
+from util import load_golden
+
+
+def _replay(name, steps=None):
+    sc, g = SCENARIOS[name], load_golden(name)
+    cfg = sc["cfg"]
+    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=sc["num_history"])
+    log = run_scenario(orc, sc, preprocess=lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb)), steps=steps)
+    for t, rec in enumerate(log):
+        out = rec["out"]
+        assert out.sequences[0].tolist() == g[f"t{t}_ids"].tolist()
+        assert out.cache_len == int(g[f"t{t}_cache_len"])
+        assert np.abs(out.hidden.numpy() - g[f"t{t}_hidden"]).max() <= 2e-4 * (1 + np.abs(g[f"t{t}_hidden"]).max())
+        assert rec["views"] == int(g[f"t{t}_views"]) and rec["memory"] == bool(g[f"t{t}_memory"])
+    return len(log)
+
+
+def test_tiny_episode_matches_reference_fixture():
+    assert _replay("tiny_episode") == 9
+
+
+def test_true_dims_first_turn_matches_reference_fixture():
+    assert _replay("true1_episode", steps=1) == 1
+
+
+def test_preprocess_matches_reference_fixture():
+    g = load_golden("preprocess")
+    pv = O.siglip_preprocess(synthetic_frame(0, 0))
+    assert pv.shape == (3, 384, 384) and pv.dtype == np.float32
+    assert np.array_equal(pv.reshape(-1)[g["flat_idx"]], g["values"])
+    assert abs(float(pv.astype(np.float64).sum()) - float(g["sum"])) < 1e-6
+
+
+def test_cache_bookkeeping_and_incremental_equals_one_shot():
+    """a-9: after a turn cache_len = L_total + n_new - 1; next turn prefill starts at the previous EOS embed;
+    the incremental first-token of a later turn equals an uncached forward over all embeds."""
+    sc = SCENARIOS["tiny_episode"]
+    cfg = sc["cfg"]
+    w = W.synth_state_dict(cfg, SEED)
+    orc = O.OracleStreamVLN(cfg, w, num_history=2)
+    img = torch.from_numpy(O.siglip_preprocess(synthetic_frame(0, 0)))[None, None]
+    o1 = orc.generate(np.array([[11, 12, -200, 13]]), img, env_id=0, time_ids=[[0]], max_new_tokens=3)
+    L1 = orc.cache[0]["inputs_embeds"].shape[0]
+    assert L1 == 3 + 196 and o1.cache_len == L1 + 3 - 1
+    ids2 = o1.sequences[0].tolist() + [21, -200, 22]
+    o2 = orc.generate(np.array([ids2]), img, env_id=0, time_ids=[[0, 1, 2, 3, 4]], past_key_values=o1.past_key_values, max_new_tokens=1)
+    E = orc.cache[0]["inputs_embeds"]
+    assert E.shape[0] == L1 + 3 + 2 + 196
+    h = O.qwen2_forward(orc.w, cfg, E, 0, O.KVCache(cfg.layers))[-1]
+    tok, _ = O.greedy_pick(O.lm_logits(orc.w, h))
+    assert tok == int(o2.sequences[0, 0])
+    assert np.abs(h.numpy() - o2.hidden[0].numpy()).max() < 1e-4
+
+
+def test_pool_restatement_equals_interpolate():
+    from streamvln_amd.config import TINY
+    x = torch.rand(2, 729, 16)
+    ref = torch.nn.functional.interpolate(x.view(2, 27, 27, 16).permute(0, 3, 1, 2), size=[14, 14], mode="bilinear")
+    assert torch.allclose(O.pool_bilinear(TINY, x), ref.permute(0, 2, 3, 1).reshape(2, 196, 16), atol=1e-5)
