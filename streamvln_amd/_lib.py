@@ -73,6 +73,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with streamvln_amd/csrc/build.sh "
                                f"(or __graft_entry__.build()); there is no fallback path")
+        # torch first: the engine must share torch's HIP runtime (same libamdhip64 instance) so that device
+        # pointers and the GPU context are common to both; loading ours first can bind a second runtime copy.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported
