@@ -84,8 +84,9 @@ int svln_probe_read(svln_engine* h, double* total_ms, int64_t* launches, double*
 int svln_phase_times(svln_engine* h, double* vision_ms, double* prefill_ms, double* decode_ms, int reset);
 
 /* -- single-kernel entry points (device pointers in the engine dtype) for the op-level parity tests */
+/* force_cfg: 0 = heuristic, 128 = 128x128 tiles; force_split: 0 = heuristic, S >= 1 = 256x128 tiles with S K-splits */
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res,
-                 int ldr, int res_mod, int M, int N, int K, int epi);
+                 int ldr, int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
 int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps);

@@ -53,7 +53,7 @@ SIGNATURES = {
     "svln_probe_reset": (_I, [_P]),
     "svln_probe_read": (_I, [_P, _PD, _PI64, _PD]),
     "svln_phase_times": (_I, [_P, _PD, _PD, _PD, _I]),
-    "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),
+    "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
     "svln_op_rmsnorm": (_I, [_P, _P, _P, _P, _I, _I, _F]),
     "svln_op_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),

@@ -101,19 +101,49 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
         const int page = p.page_table ? p.page_table[kt] : kt;
         const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
         const char* gV = (const char*)p.Vpool + (size_t)page * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
-        // ---- stage K and Vt tiles (coalesced 16-byte loads, swizzled LDS writes)
-        for (int q = tid; q < 64 * G::HDC; q += NT) {
-            const int row = q / G::HDC, c = q - row * G::HDC;
-            *(uint4*)(sK + k_off<G>(row, c)) = *(const uint4*)(gK + (size_t)q * 16);
-        }
-        for (int q = tid; q < G::VROWS * G::VC; q += NT) {
-            const int row = q / G::VC, c = q - row * G::VC;
-            const uint4 v = *(const uint4*)(gV + (size_t)q * 16);
-            if (sizeof(T) == 4) {
-                *(uint4*)(sV + v_off_f32(row, c)) = v;
-            } else {
-                *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(v.x, v.y);
-                *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(v.z, v.w);
+        // ---- stage K and Vt tiles: coalesced 16-byte loads issued in batches (all in flight before the first
+        //      dependent LDS write), swizzled LDS writes
+        {
+            constexpr int KTOT = 64 * G::HDC, VTOT = G::VROWS * G::VC, B = WAVES == 1 ? 4 : 8;
+            constexpr int KL = (KTOT + NT - 1) / NT, VL = (VTOT + NT - 1) / NT;
+#pragma unroll
+            for (int b0 = 0; b0 < KL; b0 += B) {
+                uint4 t[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int q = tid + (b0 + u) * NT;
+                    t[u] = (b0 + u < KL && q < KTOT) ? *(const uint4*)(gK + (size_t)q * 16) : zero_chunk();
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int q = tid + (b0 + u) * NT;
+                    if (b0 + u < KL && q < KTOT) {
+                        const int row = q / G::HDC, c = q - row * G::HDC;
+                        *(uint4*)(sK + k_off<G>(row, c)) = t[u];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b0 = 0; b0 < VL; b0 += B) {
+                uint4 t[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int q = tid + (b0 + u) * NT;
+                    t[u] = (b0 + u < VL && q < VTOT) ? *(const uint4*)(gV + (size_t)q * 16) : zero_chunk();
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int q = tid + (b0 + u) * NT;
+                    if (b0 + u < VL && q < VTOT) {
+                        const int row = q / G::VC, c = q - row * G::VC;
+                        if (sizeof(T) == 4) {
+                            *(uint4*)(sV + v_off_f32(row, c)) = t[u];
+                        } else {
+                            *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(t[u].x, t[u].y);
+                            *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(t[u].z, t[u].w);
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -243,25 +273,30 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
         }
 }
 
-// merge split-KV partials: one wave per (kh, rho); lanes stride the head dim
+// merge split-KV partials: one wave per (kh, rho).  Pass 1: lane z owns split z (m_z, l_z) -> wave max / weights;
+// pass 2: lane d owns output channels d and d + 64 and sums the weighted partial rows (independent loads).
 template <typename T, int HD>
 __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
+    __shared__ float wsh[64];
     const int rho = blockIdx.x, kh = blockIdx.y, lane = threadIdx.x;
     const int kv_len = p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len;
     const int tiles = (kv_len + 63) >> 6;
-    const int nsplit = min(p.nsplit, (tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+    const int nsplit = min(min(p.nsplit, 64), (tiles + p.tiles_per_split - 1) / p.tiles_per_split);
     const size_t split_stride = (size_t)p.n_kv_total * p.rows_pad * (HD + 2);
     const float* base = p.part + ((size_t)kh * p.rows_pad + rho) * (HD + 2);
-    float mstar = -INFINITY;
-    for (int z = 0; z < nsplit; ++z) mstar = fmaxf(mstar, base[z * split_stride + HD]);
-    float lsum = 0.0f, o0 = 0.0f, o1 = 0.0f;
+    float mz = -INFINITY, lz = 0.0f;
+    if (lane < nsplit) { mz = base[lane * split_stride + HD]; lz = base[lane * split_stride + HD + 1]; }
+    const float mstar = wave_max(mz);
+    const float w = mz == -INFINITY ? 0.0f : expf(mz - mstar);
+    const float lsum = wave_sum(w * lz);
+    wsh[lane] = w;
+    __syncthreads();
+    float o0 = 0.0f, o1 = 0.0f;
     for (int z = 0; z < nsplit; ++z) {
         const float* pz = base + z * split_stride;
-        const float mz = pz[HD];
-        const float w = mz == -INFINITY ? 0.0f : expf(mz - mstar);
-        lsum += w * pz[HD + 1];
-        if (lane < HD) o0 += w * pz[lane];
-        if (lane + 64 < HD) o1 += w * pz[lane + 64];
+        const float wz = wsh[z];
+        if (lane < HD) o0 += wz * pz[lane];
+        if (lane + 64 < HD) o1 += wz * pz[lane + 64];
     }
     const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;
     const int qi = rho / p.G, qg = rho - qi * p.G;

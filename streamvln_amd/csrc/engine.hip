@@ -38,6 +38,7 @@ static thread_local std::string g_err;
 constexpr int IMAGE_TOKEN = -200, MEMORY_TOKEN = -300;   // streamvln/utils/utils.py:9,15
 constexpr int PAGE = 64;                                 // keys per KV page
 constexpr int HID_TAP_ROWS = 64;
+constexpr int PREFILL_SPLIT_ROWS = 2048;                 // split-KV prefill only when T * G fits this many rows
 
 struct Slot {            // canonical tensor -> where its rows live in the packed device layout
     void* dst; int ld; int64_t rows; int cols; RowMap map; bool filled;
@@ -101,6 +102,7 @@ public:
     int* tap_idx; float* tap_w;
     // llm workspaces
     T *x, *xn, *qkv, *attn, *hbuf, *hid_tap;
+    float* gemm_ws = nullptr; size_t gemm_ws_elems = 0;
     float* inv_freq;
     float* attn_part; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
@@ -237,15 +239,27 @@ public:
         const size_t rt = (size_t)c.max_positions;
         x = dalloc<T>(rt * H); xn = dalloc<T>(rt * H); qkv = dalloc<T>(rt * qkv_dim); attn = dalloc<T>(rt * qd); hbuf = dalloc<T>(rt * I);
         hid_tap = dalloc<T>((size_t)HID_TAP_ROWS * H);
+        {   // split-K slabs: enough for 8 splits of the widest skinny product (rows of one ViT frame batch or a 512-row prefill)
+            size_t widest = (size_t)(qkv_dim > 3 * Hv ? qkv_dim : 3 * Hv);
+            if ((size_t)Iv > widest) widest = Iv;
+            size_t rows = (size_t)c.max_frames * S > 768 ? (size_t)c.max_frames * S : 768;
+            gemm_ws_elems = 8 * rows * widest;
+            if (gemm_ws_elems > (size_t)64 << 20) gemm_ws_elems = (size_t)64 << 20;
+            gemm_ws = dalloc<float>(gemm_ws_elems);
+        }
         {
             std::vector<float> f(64);
             for (int j = 0; j < 64; ++j) f[j] = 1.0f / powf(c.rope_theta, (float)(2 * j) / 128.0f);     // modeling_qwen2.py:115
             inv_freq = dalloc<float>(64);
             HIP_CHECK(hipMemcpy(inv_freq, f.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
         }
-        tiles_per_split = 2;
+        tiles_per_split = 1;                       // decode: one 64-key page per workgroup, <= 64 splits
+        while ((pages_per_env + tiles_per_split - 1) / tiles_per_split > 64) ++tiles_per_split;
         nsplit_max = (pages_per_env + tiles_per_split - 1) / tiles_per_split;
-        attn_part = dalloc<float>((size_t)nsplit_max * nkv * 32 * 130);
+        {   // partials: decode [nsplit_max][nkv][32][130], prefill split-KV [<= 8][nkv][PREFILL_SPLIT_ROWS][130]
+            const size_t dec = (size_t)nsplit_max * nkv * 32 * 130, pre = (size_t)8 * nkv * PREFILL_SPLIT_ROWS * 130;
+            attn_part = dalloc<float>(dec > pre ? dec : pre);
+        }
         part_val = dalloc<float>(2048); part_idx = dalloc<int>(2048);
         d_token = dalloc<int>(4, true); d_top2 = dalloc<float>(4, true); d_dyn = dalloc<int>(4, true);
         d_src = dalloc<int>(rt);
@@ -350,7 +364,8 @@ public:
     GemmArgs gemm_args(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
-        a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; return a;
+        a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
+        a.force_cfg = 0; a.force_split = 0; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -433,6 +448,14 @@ public:
             a.causal = 0; a.dyn_kv_len = d_dyn + 1; a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
         } else {
             a.causal = 1; a.dyn_kv_len = nullptr; a.nsplit = 1; a.tiles_per_split = pages_per_env;
+            // few row blocks (steady turn: 12 x nkv workgroups): split the keys as well so the chip is filled
+            const int rows = Tn * a.G, wgs = ((rows + 127) / 128) * nkv, tiles = (kv_len + PAGE - 1) / PAGE;
+            if (rows <= PREFILL_SPLIT_ROWS && wgs < 128 && tiles >= 4) {
+                int ns = (256 + wgs - 1) / wgs;
+                if (ns > 8) ns = 8;
+                if (ns > tiles / 2) ns = tiles / 2;
+                if (ns > 1) { a.nsplit = ns; a.tiles_per_split = (tiles + ns - 1) / ns; a.rows_pad = PREFILL_SPLIT_ROWS; }
+            }
         }
         return a;
     }
@@ -447,7 +470,11 @@ public:
             RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq;
             r.T = Tn; r.nq = nq; r.nkv = nkv; r.P = P; r.dyn_pos = nullptr;
             launch_rope_kv<T>(st, r);
-            launch_attention<T>(st, llm_attn_args(L, e, qkv, qkv_dim, attn, qd, Tn, P, P + Tn, false), 128, 4);
+            {
+                AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, Tn, P, P + Tn, false);
+                launch_attention<T>(st, a, 128, 4);
+                if (a.nsplit > 1) launch_attention_combine<T>(st, a, 128);
+            }
             launch_gemm<T>(st, gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, Tn, H, qd, EPI_NONE));
             launch_rmsnorm<T>(st, x, L.post_norm, xn, Tn, H, c.rms_eps);
             launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, Tn, 2 * I, H, EPI_SWIGLU));
@@ -644,7 +671,7 @@ public:
     }
 
     // ------------------------------------------------------------------------------- op-level entry points
-    void op_gemm(const GemmArgs& a) override { launch_gemm<T>(st, a); sync(); }
+    void op_gemm(const GemmArgs& a0) override { GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; launch_gemm<T>(st, a); sync(); }
     void op_gemv(GemvArgs a, int32_t* host_token) override {
         a.part_val = part_val; a.part_idx = part_idx;
         launch_gemv<T>(st, a);
@@ -671,13 +698,14 @@ public:
         if (ctx_T > 0) { r.qkv = const_cast<void*>(ctx); r.T = ctx_T; r.P = 0; launch_rope_kv<T>(st, r); }
         r.qkv = qkv_new; r.T = Tn; r.P = P; launch_rope_kv<T>(st, r);
         AttnArgs a = llm_attn_args(L, e, qkv_new, ld, out, o_stride, Tn, P, P + Tn, false);
-        if (nsplit > 1) {
+        if (nsplit > 1) {           // decode-style: one wave per kv head and key page
             REQUIRE(Tn * (nq / nkv) <= 32, "split-KV path takes at most 32 rows per kv head");
-            a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
+            a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split; a.rows_pad = 32;
             launch_attention<T>(st, a, 128, 1);
             launch_attention_combine<T>(st, a, 128);
-        } else {
+        } else {                    // prefill: engine heuristic (may split the keys for few row blocks)
             launch_attention<T>(st, a, 128, 4);
+            if (a.nsplit > 1) launch_attention_combine<T>(st, a, 128);
         }
         sync();
         reset_env(0);
@@ -750,10 +778,10 @@ int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes
 int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN h->impl->phase_times(v, p, d, reset); API_END }
 
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
-                 int res_mod, int M, int N, int K, int epi) {
+                 int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split) {
     API_BEGIN
     GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
-    a.M = M; a.N = N; a.K = K; a.epi = epi;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = nullptr; a.ws_elems = 0; a.nsplit = 1; a.force_cfg = force_cfg; a.force_split = force_split;
     h->impl->op_gemm(a);
     API_END
 }

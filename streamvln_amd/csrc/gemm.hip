@@ -1,17 +1,23 @@
 // MFMA GEMM  C[M,N] = epi(A[M,K] . W[N,K]^T + bias) + res   for the dense QKV / MLP / projector /
 // patch-embed products (prefill and vision; decode uses gemv.hip).
 //
-// Structure (gfx950): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave a
-// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators), K consumed 128 bytes per row per stage
-// (64 bf16 / 32 fp32), two LDS stages, register-staged prefetch of stage t+1 issued before the
-// MFMAs of stage t and written after them (one barrier per stage).  LDS rows are 128 B; the
-// 16-byte chunk index is XOR-swizzled with (row>>1)&7 so the 16 lanes of every ds_read_b128
-// group hit 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
-// Workgroup ids are remapped so that the 8 XCDs each own a contiguous band of tiles (operand
+// One kernel template, two tile configurations (each wave always owns a 64x64 sub-tile = 2x2 MFMA
+// 32x32 accumulators; operands staged global -> registers -> XOR-swizzled LDS, two LDS stages, the
+// loads of stage t+1 issued before the MFMAs of stage t and written after them, one barrier per stage):
+//   * 128x128 tile, 4 waves, 128 B of K per row per stage        -- large M (window-restart prefill, T ~ 1952)
+//   * 256x128 tile, 8 waves,  64 B of K per row per stage, split-K over grid -- skinny M (steady prefill
+//     T ~ 212, episode start 376, ViT 729 rows): the whole M extent sits in one or a few row tiles so
+//     every weight byte is streamed from HBM once, and K is split so that >= ~256 workgroups exist
+//     (one per CU).  Split-K partials go to fp32 slabs [split][M][N] (plain coalesced stores) and a
+//     second launch sums them and applies the epilogue (bias / GELU / SwiGLU / residual) -- the
+//     launch-boundary reduce, which is cheaper than an in-launch seam at these sizes.
+// LDS rows are 128 B (64 B): the 16-byte chunk index is XOR-swizzled with the row bits above the
+// 256-byte bank row so the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots.
+// Workgroup ids are remapped so that each of the 8 XCDs owns a contiguous band of tiles (operand
 // panels shared through the XCD's private L2).
 //
-// Roofline: MFMA-bound for M >= ~512; at M ~ 212 (steady prefill turn) the weight stream
-// (HBM) and MFMA times are comparable.  Algorithmic flops = 2*M*N*K.
+// Roofline: MFMA-bound for M >= ~512; at M ~ 212 the weight stream (HBM) bounds it.
+// Algorithmic flops = 2*M*N*K, algorithmic bytes = (M*K + N*K + M*N) * sizeof(T).
 #include "common.h"
 #include "kernels.h"
 
@@ -19,56 +25,86 @@ namespace svln {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;              // ROWB = bytes of K per row per stage
-constexpr int STAGE_BYTES = (BM + BN) * ROWB;              // 32 KiB
+template <int BM_, int BN_, int WM_, int WN_, int ROWB_> struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ROWB = ROWB_;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int CH = ROWB / 16;                      // 16-byte chunks per row per stage
+    static constexpr int ROWS_PER_BANKROW = 256 / ROWB;       // 2 or 4
+    static constexpr int SH = ROWS_PER_BANKROW == 2 ? 1 : 2;
+    static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    static constexpr int A_LOADS = BM * CH / THREADS, W_LOADS = BN * CH / THREADS;
+    static_assert(BM / WM == 64 && BN / WN == 64, "each wave owns 64x64");
+    static_assert(BM * CH % THREADS == 0 && BN * CH % THREADS == 0, "staging must divide evenly");
+};
+using Cfg128 = TileCfg<128, 128, 2, 2, 128>;
+using Cfg256 = TileCfg<256, 128, 4, 2, 64>;
 
-SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> 1) & 7)) << 4; }
+template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+template <typename T, int EPI> SVLN_DEV float epi_act(float v) {
+    if (EPI == EPI_GELU_TANH) return gelu_tanh_f(v);
+    if (EPI == EPI_GELU_ERF) return gelu_erf_f(v);
+    return v;
+}
+
+template <typename T, int EPI, typename C, bool SPLITK>
+__global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elt<T>::PER_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / C::WN, wc = wave % C::WN;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int nwg = tiles_m * tiles_n;
-    // XCD-aware bijective remap (blocks b, b+8, ... share an XCD): give each XCD a contiguous band
+    const int tiles_n = (p.N + C::BN - 1) / C::BN;
+    const int tiles_m = (p.M + C::BM - 1) / C::BM;
+    const int nsplit = SPLITK ? p.nsplit : 1;
+    const int nwg = tiles_m * tiles_n * nsplit;
     int bid = blockIdx.x;
-    {
+    {   // XCD-aware bijective remap (blocks b, b+8, ... share an XCD): give each XCD a contiguous band
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    // walk tiles column-major inside the band so consecutive blocks share the W panel
-    const int bn = bid / tiles_m, bm = bid % tiles_m;
-    const int row0 = bm * BM, col0 = bn * BN;
+    // order: row tile fastest (they share the W panel), then K split, then column tile
+    const int bm = bid % tiles_m;
+    const int ks = (bid / tiles_m) % nsplit;
+    const int bn = bid / (tiles_m * nsplit);
+    const int row0 = bm * C::BM, col0 = bn * C::BN;
     const int kchunks = p.K / EPC;
-    const int nkt = (kchunks + 7) >> 3;
+    const int stages_total = (kchunks + C::CH - 1) / C::CH;
+    const int stages_per = (stages_total + nsplit - 1) / nsplit;
+    const int st_begin = ks * stages_per;
+    const int st_end = min(stages_total, st_begin + stages_per);
 
     const T* A = (const T*)p.A;
     const T* W = (const T*)p.W;
 
-    uint4 ra[4], rw[4];
-    auto load_stage = [&](int kt) {
+    uint4 ra[C::A_LOADS], rw[C::W_LOADS];
+    auto load_stage = [&](int st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, kc = kt * 8 + (q & 7);
-            const int gr = row0 + r, gc = col0 + r;
+        for (int i = 0; i < C::A_LOADS; ++i) {
+            const int q = tid + C::THREADS * i, r = q / C::CH, kc = st * C::CH + (q % C::CH);
+            const int gr = row0 + r;
             ra[i] = (gr < p.M && kc < kchunks) ? *(const uint4*)(A + (size_t)gr * p.lda + (size_t)kc * EPC) : zero_chunk();
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_LOADS; ++i) {
+            const int q = tid + C::THREADS * i, r = q / C::CH, kc = st * C::CH + (q % C::CH);
+            const int gc = col0 + r;
             rw[i] = (gc < p.N && kc < kchunks) ? *(const uint4*)(W + (size_t)gc * p.ldw + (size_t)kc * EPC) : zero_chunk();
         }
     };
     auto store_stage = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES;
-        char* sw = sa + BM * ROWB;
+        char* sa = smem + buf * C::STAGE_BYTES;
+        char* sw = sa + C::BM * C::ROWB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            const int off = r * ROWB + swz(r, c);
-            *(uint4*)(sa + off) = ra[i];
-            *(uint4*)(sw + off) = rw[i];
+        for (int i = 0; i < C::A_LOADS; ++i) {
+            const int q = tid + C::THREADS * i, r = q / C::CH, c = q % C::CH;
+            *(uint4*)(sa + r * C::ROWB + swz<C>(r, c)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_LOADS; ++i) {
+            const int q = tid + C::THREADS * i, r = q / C::CH, c = q % C::CH;
+            *(uint4*)(sw + r * C::ROWB + swz<C>(r, c)) = rw[i];
         }
     };
 
@@ -80,39 +116,58 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) load_stage(kt + 1);
-        const char* sa = smem + (kt & 1) * STAGE_BYTES;
-        const char* sw = sa + BM * ROWB;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint4 a[2], b[2];
-            const int c = 2 * s + h;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wr * 64 + i * 32 + r32;
-                a[i] = *(const uint4*)(sa + r * ROWB + swz(r, c));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wc * 64 + j * 32 + r32;
-                b[j] = *(const uint4*)(sw + r * ROWB + swz(r, c));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma_chunk<T>(a[i], b[j], acc[i][j]);
-        }
-        if (more) store_stage((kt + 1) & 1);
+    if (st_begin < st_end) {
+        load_stage(st_begin);
+        store_stage(0);
         __syncthreads();
+        for (int st = st_begin; st < st_end; ++st) {
+            const int buf = (st - st_begin) & 1;
+            const bool more = st + 1 < st_end;
+            if (more) load_stage(st + 1);
+            const char* sa = smem + buf * C::STAGE_BYTES;
+            const char* sw = sa + C::BM * C::ROWB;
+#pragma unroll
+            for (int s = 0; s < C::CH / 2; ++s) {
+                uint4 a[2], b[2];
+                const int c = 2 * s + h;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = wr * 64 + i * 32 + r32;
+                    a[i] = *(const uint4*)(sa + r * C::ROWB + swz<C>(r, c));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = wc * 64 + j * 32 + r32;
+                    b[j] = *(const uint4*)(sw + r * C::ROWB + swz<C>(r, c));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma_chunk<T>(a[i], b[j], acc[i][j]);
+            }
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+        }
     }
 
-    // epilogue: D[row = A row][col = W row]; lanes 0..31 hold 32 consecutive columns
-    T* C = (T*)p.C;
+    // D[row = A row][col = W row]; lanes 0..31 hold 32 consecutive columns
+    if (SPLITK) {
+        float* slab = p.ws + (size_t)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = col0 + wc * 64 + j * 32 + r32;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                    if (m < p.M) slab[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    T* Cc = (T*)p.C;
     const T* bias = (const T*)p.bias;
     const T* res = (const T*)p.res;
     if (EPI == EPI_SWIGLU) {
@@ -123,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
-                if (m < p.M && ok_n) C[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][0][r]) * acc[i][1][r]);
+                if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][0][r]) * acc[i][1][r]);
             }
         return;
     }
@@ -138,35 +193,123 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
                 if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
-                if (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                float v = epi_act<T, EPI>(acc[i][j][r] + bv);
                 if (res) {
                     const int rr = p.res_mod > 0 ? m % p.res_mod : m;
                     v += to_f32(res[(size_t)rr * p.ldr + n]);
                 }
-                C[(size_t)m * p.ldc + n] = from_f32<T>(v);
+                Cc[(size_t)m * p.ldc + n] = from_f32<T>(v);
             }
         }
+}
+
+// sum split-K slabs + epilogue.  One thread = 4 consecutive output columns of one row.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
+    const int n_out_total = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+    const int quads = (n_out_total + 3) / 4;
+    const size_t total = (size_t)p.M * quads;
+    const size_t slab = (size_t)p.M * p.N;
+    T* Cc = (T*)p.C;
+    const T* bias = (const T*)p.bias;
+    const T* res = (const T*)p.res;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / quads), n0 = (int)(idx % quads) * 4;
+        float out[4];
+        if (EPI == EPI_SWIGLU) {
+            // output j lives in packed columns (j/32)*64 + j%32 (gate) and +32 (up); 4 consecutive j share a block
+            const int gcol = (n0 >> 5) * 64 + (n0 & 31);
+            float g[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
+            for (int s = 0; s < p.nsplit; ++s) {
+                const float4 gv = *(const float4*)(p.ws + s * slab + (size_t)m * p.N + gcol);
+                const float4 uv = *(const float4*)(p.ws + s * slab + (size_t)m * p.N + gcol + 32);
+                g[0] += gv.x; g[1] += gv.y; g[2] += gv.z; g[3] += gv.w;
+                u[0] += uv.x; u[1] += uv.y; u[2] += uv.z; u[3] += uv.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = silu_f(g[e]) * u[e];
+        } else {
+            float a[4] = {0, 0, 0, 0};
+            if (n0 + 3 < p.N) {
+                for (int s = 0; s < p.nsplit; ++s) {
+                    const float4 v = *(const float4*)(p.ws + s * slab + (size_t)m * p.N + n0);
+                    a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                }
+            } else {
+                for (int s = 0; s < p.nsplit; ++s)
+                    for (int e = 0; e < 4; ++e)
+                        if (n0 + e < p.N) a[e] += p.ws[s * slab + (size_t)m * p.N + n0 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + e;
+                if (n >= p.N) { out[e] = 0.0f; continue; }
+                float v = epi_act<T, EPI>(a[e] + (bias ? to_f32(bias[n]) : 0.0f));
+                if (res) {
+                    const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+                    v += to_f32(res[(size_t)rr * p.ldr + n]);
+                }
+                out[e] = v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n0 + e < n_out_total) Cc[(size_t)m * p.ldc + n0 + e] = from_f32<T>(out[e]);
+    }
+}
+
+template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
+    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(tiles * nsplit), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+}
+
+template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
+    if (a.M <= 0 || a.N <= 0) return;
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (tiles128 >= 384 || a.force_cfg == 128) {
+        a.nsplit = 1;
+        launch_cfg<T, EPI, Cfg128, false>(s, a, 1);
+        return;
+    }
+    const int tiles256 = ((a.M + 255) / 256) * ((a.N + 127) / 128);
+    const int stages = (a.K / EPC + Cfg256::CH - 1) / Cfg256::CH;
+    int S = (320 + tiles256 - 1) / tiles256;
+    if (S > stages / 4) S = stages / 4;
+    if (S > 16) S = 16;
+    if (a.ws == nullptr) S = 1;
+    while (S > 1 && (size_t)S * a.M * a.N > a.ws_elems) --S;
+    if (a.N % 4 != 0 || (EPI == EPI_SWIGLU && a.N % 64 != 0)) S = 1;
+    if (a.force_split > 0) S = a.force_split;
+    if (S <= 1) {
+        a.nsplit = 1;
+        launch_cfg<T, EPI, Cfg256, false>(s, a, 1);
+        return;
+    }
+    a.nsplit = S;
+    launch_cfg<T, EPI, Cfg256, true>(s, a, S);
+    const size_t work = (size_t)a.M * ((EPI == EPI_SWIGLU ? a.N / 2 : a.N) / 4 + 1);
+    int grid = (int)((work + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, a);
 }
 
 }  // namespace
 
 template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    if (tiles <= 0) return;
-    const size_t lds = 2 * STAGE_BYTES;
-    dim3 grid(tiles), block(256);
     switch (a.epi) {
-        case EPI_NONE: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_NONE>), grid, block, lds, s, a); break;
-        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU_TANH>), grid, block, lds, s, a); break;
-        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU_ERF>), grid, block, lds, s, a); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_SWIGLU>), grid, block, lds, s, a); break;
+        case EPI_NONE: launch_epi<T, EPI_NONE>(s, a); break;
+        case EPI_GELU_TANH: launch_epi<T, EPI_GELU_TANH>(s, a); break;
+        case EPI_GELU_ERF: launch_epi<T, EPI_GELU_ERF>(s, a); break;
+        case EPI_SWIGLU: launch_epi<T, EPI_SWIGLU>(s, a); break;
         default: break;
     }
 }
+
 template <typename T, int EPI> static void gemm_attr() {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, Cfg128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg128::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, Cfg256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg256::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, Cfg256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg256::STAGE_BYTES);
 }
 void gemm_init_attrs() {
     gemm_attr<bf16, EPI_NONE>(); gemm_attr<bf16, EPI_GELU_TANH>(); gemm_attr<bf16, EPI_GELU_ERF>(); gemm_attr<bf16, EPI_SWIGLU>();

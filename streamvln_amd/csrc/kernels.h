@@ -20,6 +20,9 @@ struct GemmArgs {
     const void* res; int ldr; int res_mod;
     int M, N, K;
     int epi;
+    float* ws; size_t ws_elems;   // split-K slab workspace (fp32) or null
+    int nsplit;                   // filled by the launcher
+    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 128 -> 128x128 tiles; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a);
 

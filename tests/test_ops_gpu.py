@@ -31,6 +31,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3)])
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -39,7 +40,7 @@ def chk(rc):
     (64, 256, 592, _lib.EPI_GELU_ERF, True, False),      # patch-embed K
     (1, 128, 64, _lib.EPI_NONE, False, False),           # degenerate
 ])
-def test_gemm(dtype, M, N, K, epi, bias, res):
+def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     m = engine(TINY, dtype)
     A, Wt = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1.0 / math.sqrt(K)), dtype)
     b = q(rnd((N,), 3, 0.1), dtype) if bias else None
@@ -58,8 +59,8 @@ def test_gemm(dtype, M, N, K, epi, bias, res):
     dr = r.to(dtype).cuda() if res else None
     out = torch.zeros((M, N), dtype=dtype, device="cuda")
     torch.cuda.synchronize()
-    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), N, ptr(db), ptr(dr), N, 0, M, N, K, epi))
-    assert_close(out, exp, dtype, f"gemm {M}x{N}x{K} epi{epi}")
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), N, ptr(db), ptr(dr), N, 0, M, N, K, epi, *cfgsplit))
+    assert_close(out, exp, dtype, f"gemm {M}x{N}x{K} epi{epi} cfg{cfgsplit}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -76,8 +77,13 @@ def test_gemm_swiglu_and_posmod(dtype):
     out = torch.zeros((M, I), dtype=dtype, device="cuda")
     dA, dW = A.to(dtype).cuda(), packed.to(dtype).cuda()
     torch.cuda.synchronize()
-    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU))
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU, 0, 0))
     assert_close(out, exp, dtype, "gemm swiglu")
+    for cs in [(128, 0), (0, 1), (0, 4)]:
+        out.zero_()
+        torch.cuda.synchronize()
+        chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU, *cs))
+        assert_close(out, exp, dtype, f"gemm swiglu {cs}")
     # residual with row modulo (position embedding add of the patch GEMM)
     S, N = 50, 128
     Wt, pos, b = q(rnd((N, K), 8, 0.05), dtype), q(rnd((S, N), 9), dtype), q(rnd((N,), 10), dtype)
@@ -85,7 +91,7 @@ def test_gemm_swiglu_and_posmod(dtype):
     out = torch.zeros((M, N), dtype=dtype, device="cuda")
     dW, dp, db = Wt.to(dtype).cuda(), pos.to(dtype).cuda(), b.to(dtype).cuda()
     torch.cuda.synchronize()
-    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), N, ptr(db), ptr(dp), N, S, M, N, K, _lib.EPI_NONE))
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), N, ptr(db), ptr(dp), N, S, M, N, K, _lib.EPI_NONE, 0, 2))
     assert_close(out, exp, dtype, "gemm res_mod")
 
 
