@@ -57,6 +57,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
     const int r = lane & 31, h = lane >> 5;
     const int kh = blockIdx.y;
     const int frame = kh / p.hpf, head0 = (kh % p.hpf) * p.G;
+    // first page id is independent of kv_len: fetch both scalars together (one round trip instead of two)
+    const int kt0 = blockIdx.z * p.tiles_per_split;
+    const int page0 = p.page_table ? p.page_table[kt0] : kt0;
     const int kv_len = p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len;
     const int P = p.dyn_kv_len ? kv_len - p.T : p.P;
     const int rows_total = p.T * p.G;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
     const size_t v_page_stride = (size_t)p.n_kv_total * G::VROWS * 64 * sizeof(T);
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int page = p.page_table ? p.page_table[kt] : kt;
+        const int page = kt == kt0 ? page0 : (p.page_table ? p.page_table[kt] : kt);
         const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
         const char* gV = (const char*)p.Vpool + (size_t)page * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
         // ---- stage K and Vt tiles: coalesced 16-byte loads issued in batches (all in flight before the first

@@ -104,7 +104,7 @@ public:
     T *x, *xn, *qkv, *attn, *hbuf, *hid_tap;
     float* gemm_ws = nullptr; size_t gemm_ws_elems = 0;
     float* inv_freq;
-    float* attn_part; int nsplit_max, tiles_per_split;
+    float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
     int* d_dyn;                  // [0] = position of the token being decoded, [1] = kv_len after it
     int* d_src; int* h_src;      // splice descriptors
@@ -258,7 +258,8 @@ public:
         nsplit_max = (pages_per_env + tiles_per_split - 1) / tiles_per_split;
         {   // partials: decode [nsplit_max][nkv][32][130], prefill split-KV [<= 8][nkv][PREFILL_SPLIT_ROWS][130]
             const size_t dec = (size_t)nsplit_max * nkv * 32 * 130, pre = (size_t)8 * nkv * PREFILL_SPLIT_ROWS * 130;
-            attn_part = dalloc<float>(dec > pre ? dec : pre);
+            attn_part_elems = dec > pre ? dec : pre;
+            attn_part = dalloc<float>(attn_part_elems);
         }
         part_val = dalloc<float>(2048); part_idx = dalloc<int>(2048);
         d_token = dalloc<int>(4, true); d_top2 = dalloc<float>(4, true); d_dyn = dalloc<int>(4, true);
@@ -371,12 +372,19 @@ public:
         AttnArgs a; std::memset(&a, 0, sizeof(a));
         a.Q = q; a.q_stride = ld; a.O = out; a.o_stride = o_stride; a.Kpool = vkpool; a.Vpool = vvpool; a.page_table = nullptr;
         a.n_kv_total = F * vheads; a.hpf = vheads; a.G = 1; a.T = S; a.P = 0; a.kv_len = S; a.dyn_kv_len = nullptr;
-        a.scale = 1.0f / sqrtf((float)vhd); a.causal = 0; a.nsplit = 1; a.tiles_per_split = vtiles; a.part = nullptr; a.rows_pad = 0;
+        a.scale = 1.0f / sqrtf((float)vhd); a.causal = 0; a.nsplit = 1; a.tiles_per_split = vtiles; a.part = attn_part; a.rows_pad = 0;
+        // one frame = 6 row blocks x 16 heads = 96 workgroups: split the 12 key tiles 3 ways to fill the chip
+        const int wgs = ((S + 127) / 128) * F * vheads, rows_pad = ((S + 127) / 128) * 128;
+        if (wgs < 192 && vtiles >= 6 && (size_t)3 * F * vheads * rows_pad * (vhd + 2) <= attn_part_elems) {
+            a.nsplit = 3; a.tiles_per_split = (vtiles + 2) / 3; a.rows_pad = rows_pad;
+        }
         return a;
     }
     void vit_attention(const void* qkv_buf, int ld, int F, void* out, int o_stride) {
         launch_vit_kv_pack<T>(st, qkv_buf, ld, vkpool, vvpool, F, S, vheads, vhd);
-        launch_attention<T>(st, vit_attn_args(qkv_buf, ld, F, out, o_stride), vhd, 4);
+        AttnArgs a = vit_attn_args(qkv_buf, ld, F, out, o_stride);
+        launch_attention<T>(st, a, vhd, 4);
+        if (a.nsplit > 1) launch_attention_combine<T>(st, a, vhd);
     }
     void encode_frames(const float* pixels, int F, int on_device) override {
         REQUIRE(F >= 1 && F <= c.max_frames, "n_frames out of range");
@@ -527,6 +535,13 @@ public:
         HIP_CHECK(hipMemcpyAsync(d_dyn, h_dyn, 2 * sizeof(int), hipMemcpyHostToDevice, st));
     }
 
+    // layer-0 gate/up SwiGLU GEMV with the kernel's own begin/end timestamps
+    void probe_launch(Env&) {
+        const LLayer& L = ll[0];
+        launch_gemv_timed<T>(st, gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), probe_ev[probe_used],
+                             probe_ev[probe_used + 1]);
+        probe_used += 2;
+    }
     hipGraphExec_t capture(Env& e, int lo, int hi) {
         hipGraph_t g; hipGraphExec_t ex;
         HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -559,21 +574,15 @@ public:
                 HIP_CHECK(hipGraphLaunch(graph_exec[0], st));
             } else {
                 HIP_CHECK(hipGraphLaunch(graph_exec[1], st));
-                HIP_CHECK(hipEventRecord(probe_ev[probe_used], st));
-                decode_ops(e, PROBE_OP, PROBE_OP + 1);
-                HIP_CHECK(hipEventRecord(probe_ev[probe_used + 1], st));
+                probe_launch(e);
                 HIP_CHECK(hipGraphLaunch(graph_exec[2], st));
-                probe_used += 2;
             }
         } else if (!probing) {
             decode_ops(e, 0, n_ops);
         } else {
             decode_ops(e, 0, PROBE_OP);
-            HIP_CHECK(hipEventRecord(probe_ev[probe_used], st));
-            decode_ops(e, PROBE_OP, PROBE_OP + 1);
-            HIP_CHECK(hipEventRecord(probe_ev[probe_used + 1], st));
+            probe_launch(e);
             decode_ops(e, PROBE_OP + 1, n_ops);
-            probe_used += 2;
         }
         head(x, tap_row);
         e.kv_len += 1;

@@ -266,15 +266,18 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
 template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return;
     constexpr int EPC = Elt<T>::PER_CHUNK;
-    const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tiles128 >= 384 || a.force_cfg == 128) {
+    // large M: 128x128 tiles (>= 2 waves of workgroups over 256 CUs); otherwise 256-row tiles so a weight panel is
+    // streamed by as few row tiles as possible (M <= 256: exactly once), with split-K filling the chip
+    const int tiles256_ = ((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if ((tiles256_ >= 512 && a.force_split == 0) || a.force_cfg == 128) {
         a.nsplit = 1;
         launch_cfg<T, EPI, Cfg128, false>(s, a, 1);
         return;
     }
     const int tiles256 = ((a.M + 255) / 256) * ((a.N + 127) / 128);
     const int stages = (a.K / EPC + Cfg256::CH - 1) / Cfg256::CH;
-    int S = (320 + tiles256 - 1) / tiles256;
+    int S = 448 / tiles256;            // aim for >= ~1.5 workgroups per CU; never split when one wave of tiles fills the chip
+    if (S < 1) S = 1;
     if (S > stages / 4) S = stages / 4;
     if (S > 16) S = 16;
     if (a.ws == nullptr) S = 1;

@@ -9,6 +9,8 @@
 // (bias / residual / SwiGLU / arg-max).  No LDS round trip for weights (each byte is used once).
 //
 // Roofline: HBM.  Algorithmic bytes per launch = N*K*sizeof(T) (+ x, y: negligible).
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -72,23 +74,29 @@ SVLN_DEV void load_x(const float* xs, int nch, int ci, float* f) {
     }
 }
 
-// R dot products of consecutive "logical" rows against x (rows given by pointer)
-template <typename T, int R>
-SVLN_DEV void dot_rows(const T* const (&rows)[R], const float* xs, int nch, int lane, float (&acc)[R]) {
+// R dot products against x over the chunks ci = c0 + lane + 64*k*cstep (k = 0, 1, ...) below nch.
+// XLDS: x comes from the workgroup's LDS copy (fp32, possibly RMS-normalised); otherwise each lane reads the
+// x chunk it needs straight from global memory (L2-resident, 7-37 KB) next to its weight chunks.
+template <typename T, int R, bool XLDS>
+SVLN_DEV void dot_accum(const T* const (&rows)[R], const float* xs, const T* xg, int nch, int c0, int cstep, int lane, float (&acc)[R]) {
     constexpr int EPC = Elt<T>::PER_CHUNK;
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-    int ci = lane;
-    for (; ci + 64 < nch; ci += 128) {                 // two chunks per row in flight: 2R x 1 KiB per wave
+    const int stride = 64 * cstep;
+    int ci = c0 + lane;
+    for (; ci + stride < nch; ci += 2 * stride) {      // two chunks per row in flight: 2R x 1 KiB per wave
         uint4 w0[R], w1[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             w0[r] = load_nt(rows[r] + (size_t)ci * EPC);
-            w1[r] = load_nt(rows[r] + (size_t)(ci + 64) * EPC);
+            w1[r] = load_nt(rows[r] + (size_t)(ci + stride) * EPC);
         }
         float x0[EPC], x1[EPC];
-        load_x<T>(xs, nch, ci, x0);
-        load_x<T>(xs, nch, ci + 64, x1);
+        if (XLDS) {
+            load_x<T>(xs, nch, ci, x0);
+            load_x<T>(xs, nch, ci + stride, x1);
+        } else {
+            chunk_to_f32<T>(*(const uint4*)(xg + (size_t)ci * EPC), x0);
+            chunk_to_f32<T>(*(const uint4*)(xg + (size_t)(ci + stride) * EPC), x1);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float f[EPC];
@@ -100,9 +108,10 @@ SVLN_DEV void dot_rows(const T* const (&rows)[R], const float* xs, int nch, int 
             for (int e = 0; e < EPC; ++e) acc[r] = fmaf(f[e], x1[e], acc[r]);
         }
     }
-    for (; ci < nch; ci += 64) {
+    for (; ci < nch; ci += stride) {
         float x0[EPC];
-        load_x<T>(xs, nch, ci, x0);
+        if (XLDS) load_x<T>(xs, nch, ci, x0);
+        else chunk_to_f32<T>(*(const uint4*)(xg + (size_t)ci * EPC), x0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float f[EPC];
@@ -111,8 +120,82 @@ SVLN_DEV void dot_rows(const T* const (&rows)[R], const float* xs, int nch, int 
             for (int e = 0; e < EPC; ++e) acc[r] = fmaf(f[e], x0[e], acc[r]);
         }
     }
+}
+template <typename T, int R, bool XLDS>
+SVLN_DEV void dot_rows(const T* const (&rows)[R], const float* xs, const T* xg, int nch, int c0, int cstep, int lane, float (&acc)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    dot_accum<T, R, XLDS>(rows, xs, xg, nch, c0, cstep, lane, acc);
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+}
+
+// Small-N variant (qkv / o / down projections of a decode step: N <= 8192 rows is only 224-288 workgroups of the
+// wave-per-rows kernel, i.e. < 1 per CU).  Here a workgroup owns 4 rows and its 4 waves split K (interleaved
+// 1 KiB blocks), so N/4 workgroups exist (3.5-4.5 per CU) and their prologues overlap other workgroups' streams.
+template <typename T, bool NORM>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_ksplit_kernel(GemvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ float part[GEMV_WAVES][5];
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    constexpr int R = 4;
+    const int nch = p.K / EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* W = (const T*)p.W;
+    const T* xg = (const T*)p.x;
+    const T* gg = (const T*)p.norm_w;
+    constexpr int STRIDE = 64 * GEMV_WAVES;
+    for (int n0 = blockIdx.x * R; n0 < p.N; n0 += gridDim.x * R) {
+        const T* rows[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, p.N - 1) * p.ldw;
+        float acc[R + 1];                      // acc[R] = this wave's share of sum(x^2) when NORM
+#pragma unroll
+        for (int r = 0; r <= R; ++r) acc[r] = 0.0f;
+        if (NORM) {
+            // RMSNorm folded into the product, no prologue:  y = rsqrt(mean(x^2) + eps) * sum_i W[n][i] * (g[i] * x[i]);
+            // every wave reads its K share of x and g next to its weight chunks (L2-resident, 7 KB each)
+            for (int ci = wave * 64 + lane; ci < nch; ci += STRIDE) {
+                uint4 w[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[r] = load_nt(rows[r] + (size_t)ci * EPC);
+                float xf[EPC], gf[EPC];
+                chunk_to_f32<T>(*(const uint4*)(xg + (size_t)ci * EPC), xf);
+                chunk_to_f32<T>(*(const uint4*)(gg + (size_t)ci * EPC), gf);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { acc[R] = fmaf(xf[e], xf[e], acc[R]); xf[e] *= gf[e]; }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float f[EPC];
+                    chunk_to_f32<T>(w[r], f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[r] = fmaf(f[e], xf[e], acc[r]);
+                }
+            }
+            acc[R] = wave_sum(acc[R]);
+        } else {
+            float a4[R] = {0.0f, 0.0f, 0.0f, 0.0f};
+            dot_accum<T, R, false>(rows, nullptr, xg, nch, wave * 64, GEMV_WAVES, lane, a4);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = a4[r];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r <= R; ++r) part[wave][r] = acc[r];
+        }
+        __syncthreads();
+        if (threadIdx.x < R && n0 + threadIdx.x < p.N) {
+            const int n = n0 + threadIdx.x;
+            float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+            if (NORM) v *= rsqrtf((part[0][R] + part[1][R] + part[2][R] + part[3][R]) / (float)p.K + p.eps);
+            if (p.bias) v += to_f32(((const T*)p.bias)[n]);
+            if (p.res) v += to_f32(((const T*)p.res)[n]);
+            ((T*)p.y)[n] = from_f32<T>(v);
+        }
+        __syncthreads();
+    }
 }
 
 template <typename T, int EPI>
@@ -142,7 +225,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
                 rows[2 * u + 1] = W + (gr + 32) * p.ldw;
             }
             float acc[R];
-            dot_rows<T, R>(rows, xs, nch, lane, acc);
+            dot_rows<T, R, true>(rows, xs, nullptr, nch, 0, 1, lane, acc);
             if (lane < 2 && j0 + lane < n_out) {
                 const float gt = lane == 0 ? acc[0] : acc[2], up = lane == 0 ? acc[1] : acc[3];
                 y[j0 + lane] = from_f32<T>(silu_f(gt) * up);
@@ -158,7 +241,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, p.N - 1) * p.ldw;
         float acc[R];
-        dot_rows<T, R>(rows, xs, nch, lane, acc);
+        dot_rows<T, R, true>(rows, xs, nullptr, nch, 0, 1, lane, acc);
         if (EPI == EPI_ARGMAX) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -220,26 +303,55 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, cons
 }  // namespace
 
 int gemv_grid(int N) {
-    // 4 rows per wave-iteration, 4 waves per workgroup; ~4 workgroups per CU resident, then grid-stride
-    const int groups = (N + 15) / 16;
-    return groups < 1024 ? (groups < 1 ? 1 : groups) : 1024;
+    // wave-per-4-rows kernel: 4 row groups per workgroup iteration.  Prefer a grid (<= 1280 workgroups, ~5 per CU)
+    // that divides the row groups evenly so no wave runs an extra iteration (9472 groups -> 1184 workgroups x 2).
+    const int groups = (N + 3) / 4;
+    const int wg_groups = (groups + GEMV_WAVES - 1) / GEMV_WAVES;       // workgroup-iterations needed
+    if (wg_groups <= 1280) return wg_groups < 1 ? 1 : wg_groups;
+    if (groups % GEMV_WAVES == 0)
+        for (int g = 1280; g >= 640; --g)
+            if (wg_groups % g == 0) return g;
+    return 1024;
 }
 
-template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a) {
-    const int grid = gemv_grid(a.epi == EPI_SWIGLU ? a.N / 2 * 2 : a.N);
+template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a) { launch_gemv_timed<T>(s, a, nullptr, nullptr); }
+
+// start/stop (optional) receive the kernel's own begin/end timestamps (hipExtLaunchKernelGGL)
+#define SVLN_LAUNCH(kern, grid, block, lds)                                                        \
+    do {                                                                                          \
+        if (start || stop) hipExtLaunchKernelGGL(kern, grid, block, lds, s, start, stop, 0, a);   \
+        else hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                    \
+    } while (0)
+template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, hipEvent_t start, hipEvent_t stop) {
+    dim3 b(GEMV_THREADS);
+    if (a.epi == EPI_NONE && a.N <= 8192) {
+        int grid = (a.N + 3) / 4;
+        if (grid > 2048) grid = 2048;
+        if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true>), dim3(grid), b, 0);
+        else SVLN_LAUNCH((gemv_ksplit_kernel<T, false>), dim3(grid), b, 0);
+        return;
+    }
+    const int grid = gemv_grid(a.N);
     const size_t lds = (size_t)a.K * sizeof(float);
-    dim3 g(grid), b(GEMV_THREADS);
+    dim3 g(grid);
     switch (a.epi) {
-        case EPI_NONE: hipLaunchKernelGGL((gemv_kernel<T, EPI_NONE>), g, b, lds, s, a); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemv_kernel<T, EPI_SWIGLU>), g, b, lds, s, a); break;
-        case EPI_ARGMAX: hipLaunchKernelGGL((gemv_kernel<T, EPI_ARGMAX>), g, b, lds, s, a); break;
+        case EPI_NONE: SVLN_LAUNCH((gemv_kernel<T, EPI_NONE>), g, b, lds); break;
+        case EPI_SWIGLU: SVLN_LAUNCH((gemv_kernel<T, EPI_SWIGLU>), g, b, lds); break;
+        case EPI_ARGMAX: SVLN_LAUNCH((gemv_kernel<T, EPI_ARGMAX>), g, b, lds); break;
         default: break;
     }
 }
+#undef SVLN_LAUNCH
+template void launch_gemv_timed<bf16>(hipStream_t, const GemvArgs&, hipEvent_t, hipEvent_t);
+template void launch_gemv_timed<float>(hipStream_t, const GemvArgs&, hipEvent_t, hipEvent_t);
 template <typename T, int EPI> static void gemv_attr() {
     (void)hipFuncSetAttribute((const void*)gemv_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
+template <typename T> static void gemv_ksplit_attr() {
+    (void)hipFuncSetAttribute((const void*)gemv_ksplit_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}
 void gemv_init_attrs() {
+    gemv_ksplit_attr<bf16>(); gemv_ksplit_attr<float>();
     gemv_attr<bf16, EPI_NONE>(); gemv_attr<bf16, EPI_SWIGLU>(); gemv_attr<bf16, EPI_ARGMAX>();
     gemv_attr<float, EPI_NONE>(); gemv_attr<float, EPI_SWIGLU>(); gemv_attr<float, EPI_ARGMAX>();
 }

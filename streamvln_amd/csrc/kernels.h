@@ -41,6 +41,7 @@ struct GemvArgs {
     float* part_val; int* part_idx;
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
+template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, hipEvent_t start, hipEvent_t stop);   // events get the kernel's own begin/end
 int gemv_grid(int N);                       // workgroups launch_gemv uses for N rows
 void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token,
                          float* out_top /*[2]: best, runner-up of partial maxima (diagnostic)*/);
