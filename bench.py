@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -133,7 +135,9 @@ def main():
     from streamvln_amd.eval_harness import reduce_metrics
     import torch.distributed as dist
 
-    rank, world, local = init_distributed_mode()
+    rank, world, local = init_distributed_mode(backend=a.backend)
+    if a.single_device:
+        local = 0
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP engine has no CPU fallback)"
     torch.cuda.set_device(local)
@@ -168,7 +172,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     lib.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 0)
@@ -183,7 +187,7 @@ def main():
                     "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                     "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
     # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
-    summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if world > 1 else "cpu")
+    summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     turns_total = a.steps * world
     value = NUM_FUTURE * turns_total / dt
     if rank == 0:

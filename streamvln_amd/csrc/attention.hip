@@ -71,12 +71,35 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
 
     // Q fragments (B operand of S^T): lane (r,h) holds chunk 2s+h of query row rho
     uint4 qf[G::HDC / 2];
+    const bool fused = WAVES == 1 && HD == 128 && p.fuse_rope_append;
+    const int fpos = fused ? *p.dyn_pos : 0;
     {
         const T* qrow = (const T*)p.Q + (size_t)(frame * p.T + qi) * p.q_stride + (size_t)(head0 + qg) * HD;
 #pragma unroll
         for (int s = 0; s < G::HDC / 2; ++s) {
             const int e0 = (2 * s + h) * EPC;
             qf[s] = (valid && e0 < HD) ? *(const uint4*)(qrow + e0) : zero_chunk();
+        }
+    }
+    if (WAVES == 1 && HD == 128) {
+        if (fused) {
+            // RoPE on q in registers: chunk c = 2s+h (d < 64) pairs with chunk c + HDC/2 = fragment s + HDC/4
+            const float* tab = p.rope_tab + (size_t)fpos * 128;
+#pragma unroll
+            for (int s = 0; s < G::HDC / 4; ++s) {
+                const int d0 = (2 * s + h) * EPC;
+                float x1[EPC], x2[EPC], o1[EPC], o2[EPC];
+                chunk_to_f32<T>(qf[s], x1);
+                chunk_to_f32<T>(qf[s + G::HDC / 4], x2);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float c = tab[d0 + e], sn = tab[64 + d0 + e];
+                    o1[e] = x1[e] * c - x2[e] * sn;
+                    o2[e] = x2[e] * c + x1[e] * sn;
+                }
+                qf[s] = f32_to_chunk<T>(o1);
+                qf[s + G::HDC / 4] = f32_to_chunk<T>(o2);
+            }
         }
     }
 
@@ -146,6 +169,34 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
                             *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(t[u].z, t[u].w);
                         }
                     }
+                }
+            }
+        }
+        if (WAVES == 1 && HD == 128) {
+            if (fused && kt == (fpos >> 6)) {
+                // this workgroup owns the page of the token being decoded: rope its k, append k / v to the pools and
+                // patch the LDS tiles (the staged copy of that slot is stale).  64 threads: d pairs (d, d + 64).
+                __syncthreads();
+                const int off = fpos & 63, d = tid;
+                const T* krow = (const T*)p.Q + (size_t)(p.nq_heads + kh) * 128;
+                const T* vrow = (const T*)p.Q + (size_t)(p.nq_heads + p.n_kv_total + kh) * 128;
+                const float* tab = p.rope_tab + (size_t)fpos * 128;
+                const float k1 = to_f32(krow[d]), k2 = to_f32(krow[d + 64]);
+                const float c = tab[d], sn = tab[64 + d];
+                const T ko1 = from_f32<T>(k1 * c - k2 * sn), ko2 = from_f32<T>(k2 * c + k1 * sn);
+                const T v1 = vrow[d], v2 = vrow[d + 64];
+                T* gk = (T*)(const_cast<char*>(gK)) + (size_t)off * 128;
+                T* gv = (T*)(const_cast<char*>(gV));
+                gk[d] = ko1; gk[d + 64] = ko2;
+                gv[(size_t)d * 64 + off] = v1; gv[(size_t)(d + 64) * 64 + off] = v2;
+                *(T*)(sK + k_off<G>(off, d / EPC) + (d % EPC) * sizeof(T)) = ko1;
+                *(T*)(sK + k_off<G>(off, (d + 64) / EPC) + ((d + 64) % EPC) * sizeof(T)) = ko2;
+                if (sizeof(T) == 4) {
+                    *(T*)(sV + v_off_f32(d, off >> 2) + (off & 3) * 4) = v1;
+                    *(T*)(sV + v_off_f32(d + 64, off >> 2) + (off & 3) * 4) = v2;
+                } else {
+                    *(T*)(sV + v_off_bf16(d, off >> 2) + (off & 3) * 2) = v1;
+                    *(T*)(sV + v_off_bf16(d + 64, off >> 2) + (off & 3) * 2) = v2;
                 }
             }
         }
@@ -276,6 +327,182 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
         }
 }
 
+// Decode step attention (one query position, G <= 32 q-head rows per kv head, head_dim 128): workgroup = (kv head, key
+// split) with 4 waves.  All 256 threads put the split's K / Vt page loads in flight at once (8 x 16 B per thread),
+// every wave builds the roped Q fragments and S^T = K.Q^T for the page (16 MFMAs, redundant per wave, trivial), then
+// wave w owns output channels [32w, 32w+32) of O^T = Vt.P^T.  RoPE(q), RoPE(k) + the KV append of the token being
+// decoded are fused (the workgroup that owns its page patches the LDS tile and writes the pools).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
+    using G = AttnGeom<T, 128>;
+    constexpr int EPC = G::EPC, NT = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + G::K_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int kh = blockIdx.x, z = blockIdx.y;
+    const int kt0 = z * p.tiles_per_split;
+    const int page0 = p.page_table[kt0];
+    const int pos = *p.dyn_pos;
+    const int kv_len = pos + 1;
+    const int tiles = (kv_len + 63) >> 6;
+    if (kt0 >= tiles) return;                                   // combine only reads splits below ceil(tiles / tiles_per_split)
+    const int kt_end = min(tiles, kt0 + p.tiles_per_split);
+    const size_t k_page_stride = (size_t)p.n_kv_total * 64 * 128 * sizeof(T);
+    const bool valid = r < p.G;
+
+    // roped Q fragments of row rho = r (q head kh*G + r), identical in every wave
+    uint4 qf[G::HDC / 2];
+    {
+        const T* qrow = (const T*)p.Q + (size_t)(kh * p.G + (valid ? r : 0)) * 128;
+#pragma unroll
+        for (int s = 0; s < G::HDC / 2; ++s) qf[s] = valid ? *(const uint4*)(qrow + (2 * s + h) * EPC) : zero_chunk();
+        const float* tab = p.rope_tab + (size_t)pos * 128;
+#pragma unroll
+        for (int s = 0; s < G::HDC / 4; ++s) {
+            const int d0 = (2 * s + h) * EPC;
+            float x1[EPC], x2[EPC], o1[EPC], o2[EPC];
+            chunk_to_f32<T>(qf[s], x1);
+            chunk_to_f32<T>(qf[s + G::HDC / 4], x2);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float c = tab[d0 + e], sn = tab[64 + d0 + e];
+                o1[e] = x1[e] * c - x2[e] * sn;
+                o2[e] = x2[e] * c + x1[e] * sn;
+            }
+            qf[s] = f32_to_chunk<T>(o1);
+            qf[s + G::HDC / 4] = f32_to_chunk<T>(o2);
+        }
+    }
+
+    f32x16 O;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[e] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+
+    for (int kt = kt0; kt < kt_end; ++kt) {
+        const int page = kt == kt0 ? page0 : p.page_table[kt];
+        const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * 128 * sizeof(T);
+        const char* gV = (const char*)p.Vpool + (size_t)page * k_page_stride + (size_t)kh * 128 * 64 * sizeof(T);
+        constexpr int KL = 64 * G::HDC / NT, VL = 128 * G::VC / NT;
+        uint4 tk[KL], tv[VL];
+#pragma unroll
+        for (int u = 0; u < KL; ++u) tk[u] = *(const uint4*)(gK + (size_t)(tid + u * NT) * 16);
+#pragma unroll
+        for (int u = 0; u < VL; ++u) tv[u] = *(const uint4*)(gV + (size_t)(tid + u * NT) * 16);
+#pragma unroll
+        for (int u = 0; u < KL; ++u) {
+            const int q = tid + u * NT, row = q / G::HDC, c = q - row * G::HDC;
+            *(uint4*)(sK + k_off<G>(row, c)) = tk[u];
+        }
+#pragma unroll
+        for (int u = 0; u < VL; ++u) {
+            const int q = tid + u * NT, row = q / G::VC, c = q - row * G::VC;
+            if (sizeof(T) == 4) {
+                *(uint4*)(sV + v_off_f32(row, c)) = tv[u];
+            } else {
+                *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(tv[u].x, tv[u].y);
+                *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(tv[u].z, tv[u].w);
+            }
+        }
+        if (kt == (pos >> 6)) {
+            __syncthreads();
+            if (tid < 64) {
+                const int off = pos & 63, d = tid;
+                const T* krow = (const T*)p.Q + (size_t)(p.nq_heads + kh) * 128;
+                const T* vrow = (const T*)p.Q + (size_t)(p.nq_heads + p.n_kv_total + kh) * 128;
+                const float* tab = p.rope_tab + (size_t)pos * 128;
+                const float k1 = to_f32(krow[d]), k2 = to_f32(krow[d + 64]);
+                const float c = tab[d], sn = tab[64 + d];
+                const T ko1 = from_f32<T>(k1 * c - k2 * sn), ko2 = from_f32<T>(k2 * c + k1 * sn);
+                const T v1 = vrow[d], v2 = vrow[d + 64];
+                T* gk = (T*)(const_cast<char*>(gK)) + (size_t)off * 128;
+                T* gv = (T*)(const_cast<char*>(gV));
+                gk[d] = ko1; gk[d + 64] = ko2;
+                gv[(size_t)d * 64 + off] = v1; gv[(size_t)(d + 64) * 64 + off] = v2;
+                *(T*)(sK + k_off<G>(off, d / EPC) + (d % EPC) * sizeof(T)) = ko1;
+                *(T*)(sK + k_off<G>(off, (d + 64) / EPC) + ((d + 64) % EPC) * sizeof(T)) = ko2;
+                if (sizeof(T) == 4) {
+                    *(T*)(sV + v_off_f32(d, off >> 2) + (off & 3) * 4) = v1;
+                    *(T*)(sV + v_off_f32(d + 64, off >> 2) + (off & 3) * 4) = v2;
+                } else {
+                    *(T*)(sV + v_off_bf16(d, off >> 2) + (off & 3) * 2) = v1;
+                    *(T*)(sV + v_off_bf16(d + 64, off >> 2) + (off & 3) * 2) = v2;
+                }
+            }
+        }
+        __syncthreads();
+
+        f32x16 S[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[j][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < G::HDC / 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_chunk<T>(*(const uint4*)(sK + k_off<G>(j * 32 + r, 2 * s + h)), qf[s], S[j]);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 64 + j * 32 + acc_row(e, lane);
+                const float sv = key < kv_len ? S[j][e] * p.scale : -INFINITY;
+                S[j][e] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m, mloc);          // the first key of every processed tile is valid -> finite
+        const float alpha = expf(m - mnew);
+        float psum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = expf(S[j][e] - mnew);
+                S[j][e] = pv;
+                psum += pv;
+            }
+        l = l * alpha + psum;
+        m = mnew;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[e] *= alpha;
+        const int row = wave * 32 + r;                // this wave's 32 output channels
+        if (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int j = ks >> 1, b0 = 8 * (ks & 1);
+                const uint4 pf = make_uint4(pack_bf16x2(S[j][b0 + 0], S[j][b0 + 1]), pack_bf16x2(S[j][b0 + 2], S[j][b0 + 3]),
+                                            pack_bf16x2(S[j][b0 + 4], S[j][b0 + 5]), pack_bf16x2(S[j][b0 + 6], S[j][b0 + 7]));
+                const uint2 lo = *(const uint2*)(sV + v_off_bf16(row, 4 * ks + h));
+                const uint2 hi = *(const uint2*)(sV + v_off_bf16(row, 4 * ks + 2 + h));
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)),
+                                                            __builtin_bit_cast(bf16x8, pf), O, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const uint4 a = *(const uint4*)(sV + v_off_f32(row, j * 8 + 2 * g4 + h));
+                    O = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), S[j][4 * g4 + 0], O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), S[j][4 * g4 + 1], O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), S[j][4 * g4 + 2], O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), S[j][4 * g4 + 3], O, 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (!valid) return;
+    float* dst = p.part + (((size_t)z * p.n_kv_total + kh) * p.rows_pad + r) * 130;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[wave * 32 + acc_row(e, lane)] = O[e];
+    if (wave == 0 && h == 0) { dst[128] = m; dst[129] = l; }
+}
+
 // merge split-KV partials: one wave per (kh, rho).  Pass 1: lane z owns split z (m_z, l_z) -> wave max / weights;
 // pass 2: lane d owns output channels d and d + 64 and sums the weighted partial rows (independent loads).
 template <typename T, int HD>
@@ -320,6 +547,11 @@ template <typename T, int HD, int WAVES> void launch_attn_t(hipStream_t s, const
 }  // namespace
 
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves) {
+    if (head_dim == 128 && waves == 1 && a.fuse_rope_append && a.T == 1) {
+        using G = AttnGeom<T, 128>;
+        hipLaunchKernelGGL((attn_decode_kernel<T>), dim3(a.n_kv_total, a.nsplit), dim3(256), G::K_TILE_BYTES + G::V_TILE_BYTES, s, a);
+        return;
+    }
     if (head_dim == 128) {
         if (waves == 1) launch_attn_t<T, 128, 1>(s, a); else launch_attn_t<T, 128, 4>(s, a);
     } else if (head_dim == 72) {
@@ -337,6 +569,7 @@ template <typename T, int HD, int WAVES> static void attn_attr() {
                               G::K_TILE_BYTES + G::V_TILE_BYTES);
 }
 void attention_init_attrs() {
+    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnGeom<float, 128>::K_TILE_BYTES + AttnGeom<float, 128>::V_TILE_BYTES);
     attn_attr<bf16, 128, 1>(); attn_attr<bf16, 128, 4>(); attn_attr<bf16, 72, 1>(); attn_attr<bf16, 72, 4>();
     attn_attr<float, 128, 1>(); attn_attr<float, 128, 4>(); attn_attr<float, 72, 1>(); attn_attr<float, 72, 4>();
 }

@@ -102,8 +102,8 @@ public:
     int* tap_idx; float* tap_w;
     // llm workspaces
     T *x, *xn, *qkv, *attn, *hbuf, *hid_tap;
-    float* gemm_ws = nullptr; size_t gemm_ws_elems = 0;
-    float* inv_freq;
+    float* gemm_ws = nullptr; size_t gemm_ws_elems = 0; void* zero_line = nullptr;
+    float* inv_freq; float* rope_tab;
     float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
     int* d_dyn;                  // [0] = position of the token being decoded, [1] = kv_len after it
@@ -246,12 +246,15 @@ public:
             gemm_ws_elems = 8 * rows * widest;
             if (gemm_ws_elems > (size_t)64 << 20) gemm_ws_elems = (size_t)64 << 20;
             gemm_ws = dalloc<float>(gemm_ws_elems);
+            zero_line = dalloc<char>(256, true);
         }
         {
             std::vector<float> f(64);
             for (int j = 0; j < 64; ++j) f[j] = 1.0f / powf(c.rope_theta, (float)(2 * j) / 128.0f);     // modeling_qwen2.py:115
             inv_freq = dalloc<float>(64);
             HIP_CHECK(hipMemcpy(inv_freq, f.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+            rope_tab = dalloc<float>((size_t)c.max_positions * 128);
+            launch_rope_table(st, rope_tab, inv_freq, c.max_positions);
         }
         tiles_per_split = 1;                       // decode: one 64-key page per workgroup, <= 64 splits
         while ((pages_per_env + tiles_per_split - 1) / tiles_per_split > 64) ++tiles_per_split;
@@ -366,7 +369,7 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.force_cfg = 0; a.force_split = 0; return a;
+        a.zeros = zero_line; a.w_tiled = 0; a.force_cfg = 0; a.force_split = 0; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -454,6 +457,7 @@ public:
         a.part = attn_part; a.rows_pad = 32;
         if (decode) {
             a.causal = 0; a.dyn_kv_len = d_dyn + 1; a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
+            a.fuse_rope_append = 1; a.rope_tab = rope_tab; a.dyn_pos = d_dyn; a.nq_heads = nq;
         } else {
             a.causal = 1; a.dyn_kv_len = nullptr; a.nsplit = 1; a.tiles_per_split = pages_per_env;
             // few row blocks (steady turn: 12 x nkv workgroups): split the keys as well so the chip is filled
@@ -475,7 +479,7 @@ public:
             const LLayer& L = ll[i];
             launch_rmsnorm<T>(st, x, L.in_norm, xn, Tn, H, c.rms_eps);
             launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, Tn, qkv_dim, H, EPI_NONE));
-            RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq;
+            RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.rope_tab = rope_tab;
             r.T = Tn; r.nq = nq; r.nkv = nkv; r.P = P; r.dyn_pos = nullptr;
             launch_rope_kv<T>(st, r);
             {
@@ -504,8 +508,9 @@ public:
     }
     // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_dyn,
     // d_token) so any sub-range [lo, hi) of the sequence can be captured once and graph-replayed.
-    // Op ids: 0 = embedding gather, then 7 per layer; the layer-0 gate/up GEMV is op PROBE_OP.
-    static constexpr int OPS_PER_LAYER = 7, PROBE_OP = 1 + 5;
+    // Op ids: 0 = embedding gather, then 6 per layer (qkv GEMV, attention with fused RoPE + KV append, combine, o GEMV,
+    // gate/up GEMV, down GEMV); the layer-0 gate/up GEMV is op PROBE_OP.
+    static constexpr int OPS_PER_LAYER = 6, PROBE_OP = 1 + 4;
     int total_ops() const { return 1 + c.layers * OPS_PER_LAYER; }
     void decode_ops(Env& e, int lo, int hi) {
         const int qd = nq * 128;
@@ -515,11 +520,6 @@ public:
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
             if (on()) launch_gemv<T>(st, gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE));
-            if (on()) {
-                RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq;
-                r.T = 1; r.nq = nq; r.nkv = nkv; r.P = 0; r.dyn_pos = d_dyn;
-                launch_rope_kv<T>(st, r);
-            }
             AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, 1, 0, 0, true);
             if (on()) launch_attention<T>(st, a, 128, 1);
             if (on()) launch_attention_combine<T>(st, a, 128);
@@ -680,7 +680,7 @@ public:
     }
 
     // ------------------------------------------------------------------------------- op-level entry points
-    void op_gemm(const GemmArgs& a0) override { GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; launch_gemm<T>(st, a); sync(); }
+    void op_gemm(const GemmArgs& a0) override { GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.zeros = zero_line; launch_gemm<T>(st, a); sync(); }
     void op_gemv(GemvArgs a, int32_t* host_token) override {
         a.part_val = part_val; a.part_idx = part_idx;
         launch_gemv<T>(st, a);
@@ -702,7 +702,7 @@ public:
         reset_env(0);
         ensure_pages(e, P + Tn);
         const LLayer& L = ll[0];
-        RopeKvArgs r; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.inv_freq = inv_freq; r.nq = nq; r.nkv = nkv; r.dyn_pos = nullptr;
+        RopeKvArgs r; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.rope_tab = rope_tab; r.nq = nq; r.nkv = nkv; r.dyn_pos = nullptr;
         r.ld = ld;
         if (ctx_T > 0) { r.qkv = const_cast<void*>(ctx); r.T = ctx_T; r.P = 0; launch_rope_kv<T>(st, r); }
         r.qkv = qkv_new; r.T = Tn; r.P = P; launch_rope_kv<T>(st, r);
@@ -790,7 +790,7 @@ int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw,
                  int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split) {
     API_BEGIN
     GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
-    a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = nullptr; a.ws_elems = 0; a.nsplit = 1; a.force_cfg = force_cfg; a.force_split = force_split;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = nullptr; a.ws_elems = 0; a.nsplit = 1; a.zeros = nullptr; a.w_tiled = 0; a.force_cfg = force_cfg; a.force_split = force_split;
     h->impl->op_gemm(a);
     API_END
 }

@@ -5,7 +5,8 @@
 // 32x32 accumulators; operands staged global -> registers -> XOR-swizzled LDS, two LDS stages, the
 // loads of stage t+1 issued before the MFMAs of stage t and written after them, one barrier per stage):
 //   * 128x128 tile, 4 waves, 128 B of K per row per stage        -- large M (window-restart prefill, T ~ 1952)
-//   * 256x128 tile, 8 waves,  64 B of K per row per stage, split-K over grid -- skinny M (steady prefill
+//   * 256x128 tile, 8 waves, 128 B of K per row per stage, TWO register sets in flight (two stages of HBM latency
+//     tolerance), split-K over grid -- skinny M (steady prefill
 //     T ~ 212, episode start 376, ViT 729 rows): the whole M extent sits in one or a few row tiles so
 //     every weight byte is streamed from HBM once, and K is split so that >= ~256 workgroups exist
 //     (one per CU).  Split-K partials go to fp32 slabs [split][M][N] (plain coalesced stores) and a
@@ -25,8 +26,10 @@ namespace svln {
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int ROWB_> struct TileCfg {
+template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_> struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ROWB = ROWB_;
+    static constexpr bool DEEP = DEEP_;
+    static constexpr int NBUF = NBUF_;                        // LDS ring depth of the direct-to-LDS (glds) pipeline
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int CH = ROWB / 16;                      // 16-byte chunks per row per stage
     static constexpr int ROWS_PER_BANKROW = 256 / ROWB;       // 2 or 4
@@ -36,8 +39,8 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_> struct TileCfg {
     static_assert(BM / WM == 64 && BN / WN == 64, "each wave owns 64x64");
     static_assert(BM * CH % THREADS == 0 && BN * CH % THREADS == 0, "staging must divide evenly");
 };
-using Cfg128 = TileCfg<128, 128, 2, 2, 128>;
-using Cfg256 = TileCfg<256, 128, 4, 2, 64>;
+using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
+using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
 
@@ -77,34 +80,42 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
 
     const T* A = (const T*)p.A;
     const T* W = (const T*)p.W;
+    const bool w_nt = tiles_m == 1 && !(p.force_cfg & 0x1000);
 
-    uint4 ra[C::A_LOADS], rw[C::W_LOADS];
-    auto load_stage = [&](int st) {
+    struct Regs { uint4 a[C::A_LOADS]; uint4 w[C::W_LOADS]; };
+    auto load_stage = [&](Regs& rg, int st) {
 #pragma unroll
         for (int i = 0; i < C::A_LOADS; ++i) {
             const int q = tid + C::THREADS * i, r = q / C::CH, kc = st * C::CH + (q % C::CH);
             const int gr = row0 + r;
-            ra[i] = (gr < p.M && kc < kchunks) ? *(const uint4*)(A + (size_t)gr * p.lda + (size_t)kc * EPC) : zero_chunk();
+            rg.a[i] = (gr < p.M && kc < kchunks) ? *(const uint4*)(A + (size_t)gr * p.lda + (size_t)kc * EPC) : zero_chunk();
         }
 #pragma unroll
         for (int i = 0; i < C::W_LOADS; ++i) {
             const int q = tid + C::THREADS * i, r = q / C::CH, kc = st * C::CH + (q % C::CH);
             const int gc = col0 + r;
-            rw[i] = (gc < p.N && kc < kchunks) ? *(const uint4*)(W + (size_t)gc * p.ldw + (size_t)kc * EPC) : zero_chunk();
+            // a weight panel that only ONE row tile reads is a read-once stream: non-temporal, so it does not evict
+            // the activation panel (re-read by every column tile) from the XCD's L2
+            if (gc < p.N && kc < kchunks) {
+                const T* src = W + (size_t)gc * p.ldw + (size_t)kc * EPC;
+                rg.w[i] = w_nt ? load_nt(src) : *(const uint4*)src;
+            } else {
+                rg.w[i] = zero_chunk();
+            }
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](const Regs& rg, int buf) {
         char* sa = smem + buf * C::STAGE_BYTES;
         char* sw = sa + C::BM * C::ROWB;
 #pragma unroll
         for (int i = 0; i < C::A_LOADS; ++i) {
             const int q = tid + C::THREADS * i, r = q / C::CH, c = q % C::CH;
-            *(uint4*)(sa + r * C::ROWB + swz<C>(r, c)) = ra[i];
+            *(uint4*)(sa + r * C::ROWB + swz<C>(r, c)) = rg.a[i];
         }
 #pragma unroll
         for (int i = 0; i < C::W_LOADS; ++i) {
             const int q = tid + C::THREADS * i, r = q / C::CH, c = q % C::CH;
-            *(uint4*)(sw + r * C::ROWB + swz<C>(r, c)) = rw[i];
+            *(uint4*)(sw + r * C::ROWB + swz<C>(r, c)) = rg.w[i];
         }
     };
 
@@ -116,37 +127,63 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if (st_begin < st_end) {
-        load_stage(st_begin);
-        store_stage(0);
-        __syncthreads();
-        for (int st = st_begin; st < st_end; ++st) {
-            const int buf = (st - st_begin) & 1;
-            const bool more = st + 1 < st_end;
-            if (more) load_stage(st + 1);
-            const char* sa = smem + buf * C::STAGE_BYTES;
-            const char* sw = sa + C::BM * C::ROWB;
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * C::STAGE_BYTES;
+        const char* sw = sa + C::BM * C::ROWB;
 #pragma unroll
-            for (int s = 0; s < C::CH / 2; ++s) {
-                uint4 a[2], b[2];
-                const int c = 2 * s + h;
+        for (int s = 0; s < C::CH / 2; ++s) {
+            uint4 a[2], b[2];
+            const int c = 2 * s + h;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r = wr * 64 + i * 32 + r32;
-                    a[i] = *(const uint4*)(sa + r * C::ROWB + swz<C>(r, c));
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r = wc * 64 + j * 32 + r32;
-                    b[j] = *(const uint4*)(sw + r * C::ROWB + swz<C>(r, c));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) mma_chunk<T>(a[i], b[j], acc[i][j]);
+            for (int i = 0; i < 2; ++i) {
+                const int r = wr * 64 + i * 32 + r32;
+                a[i] = *(const uint4*)(sa + r * C::ROWB + swz<C>(r, c));
             }
-            if (more) store_stage(buf ^ 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wc * 64 + j * 32 + r32;
+                b[j] = *(const uint4*)(sw + r * C::ROWB + swz<C>(r, c));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma_chunk<T>(a[i], b[j], acc[i][j]);
+        }
+    };
+
+    const int n = st_end - st_begin;
+    if (n > 0) {
+        if (C::DEEP) {
+            // two register sets: while stage t is consumed from LDS, stage t+1 is landing in one set and stage t+2 has
+            // just been issued into the other (two stages of HBM latency tolerance with two LDS buffers)
+            Regs r0, r1;
+            load_stage(r0, st_begin);
+            if (n > 1) load_stage(r1, st_begin + 1);
+            store_stage(r0, 0);
             __syncthreads();
+            for (int i = 0; i < n; i += 2) {
+                if (i + 2 < n) load_stage(r0, st_begin + i + 2);
+                compute(0);
+                if (i + 1 < n) store_stage(r1, 1);
+                __syncthreads();
+                if (i + 1 >= n) break;
+                if (i + 3 < n) load_stage(r1, st_begin + i + 3);
+                compute(1);
+                if (i + 2 < n) store_stage(r0, 0);
+                __syncthreads();
+            }
+        } else {
+            Regs r0;
+            load_stage(r0, st_begin);
+            store_stage(r0, 0);
+            __syncthreads();
+            for (int i = 0; i < n; ++i) {
+                const bool more = i + 1 < n;
+                if (more) load_stage(r0, st_begin + i + 1);
+                compute(i & 1);
+                if (more) store_stage(r0, (i & 1) ^ 1);
+                __syncthreads();
+            }
         }
     }
 
@@ -199,6 +236,193 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
                     v += to_f32(res[(size_t)rr * p.ldr + n]);
                 }
                 Cc[(size_t)m * p.ldc + n] = from_f32<T>(v);
+            }
+        }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Same tiles and epilogues, operands staged with LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR or
+// ds_write hop).  One wave instruction fills 1 KiB of LDS = 8 consecutive 128-byte tile rows, lane l -> row l/8,
+// physical chunk l%8; the XOR swizzle is applied on the per-lane SOURCE address (the LDS image must stay lane-linear).
+// Ring of NBUF stage buffers, NBUF-1 stages in flight behind a counted s_waitcnt vmcnt + one raw s_barrier per stage:
+//   wait(stage i landed) ; barrier ; issue stage i+NBUF-1 into the buffer read in iteration i-1 ; MFMAs on stage i.
+// Rows beyond M / N are clamped to the last valid row (their outputs are never stored); K-tail chunks read a zero line.
+template <typename T, int EPI, typename C, bool SPLITK>
+__global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    static_assert(C::ROWB == 128 && C::CH == 8, "glds path: 128-byte tile rows (4 macro steps per stage)");
+    constexpr int WAVES = C::THREADS / 64;
+    constexpr int BLK_A = C::BM * C::ROWB / 1024, BLK_W = C::BN * C::ROWB / 1024;
+    constexpr int PER_WAVE = (BLK_A + BLK_W) / WAVES;
+    constexpr int D = C::NBUF - 1;
+    static_assert((BLK_A + BLK_W) % WAVES == 0, "blocks must divide over waves");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / C::WN, wc = wave % C::WN;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + C::BN - 1) / C::BN;
+    const int tiles_m = (p.M + C::BM - 1) / C::BM;
+    const int nsplit = SPLITK ? p.nsplit : 1;
+    const int nwg = tiles_m * tiles_n * nsplit;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int bm = bid % tiles_m;
+    const int ks = (bid / tiles_m) % nsplit;
+    const int bn = bid / (tiles_m * nsplit);
+    const int row0 = bm * C::BM, col0 = bn * C::BN;
+    const int kchunks = p.K / EPC;
+    const int stages_total = (kchunks + C::CH - 1) / C::CH;
+    const int stages_per = (stages_total + nsplit - 1) / nsplit;
+    const int st_begin = ks * stages_per;
+    const int st_end = min(stages_total, st_begin + stages_per);
+    const int n = st_end - st_begin;
+
+    // per-lane source pointers (at K stage 0) and wave-uniform LDS offsets of this wave's 1-KiB blocks
+    const char* src[PER_WAVE];
+    int cj[PER_WAVE], loff[PER_WAVE], wstep[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int b = wave + WAVES * j;
+        const bool isA = b < BLK_A;
+        const int blk = isA ? b : b - BLK_A;
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
+        cj[j] = c;
+        loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
+        if (isA) src[j] = (const char*)((const T*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
+        else if (p.w_tiled) src[j] = (const char*)p.W + ((size_t)bn * stages_total * C::BN + row) * C::ROWB + c * 16;
+        else src[j] = (const char*)((const T*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
+        wstep[j] = (!isA && p.w_tiled) ? C::BN * C::ROWB : C::ROWB;
+    }
+    auto issue = [&](int st, int buf) {
+        char* base = smem + buf * C::STAGE_BYTES;
+        const bool full = (st + 1) * C::CH <= kchunks;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const char* g = src[j] + (size_t)((p.force_cfg & 0x8000) ? 0 : st) * wstep[j];    // 0x8000: timing experiment (no K advance)
+            if (!full && st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // LDS fragment reads are issued as inline asm: hipcc orders every ds_read it can see behind ALL outstanding
+    // LDS-DMA (it emits s_waitcnt vmcnt(0) before the first ds_read of the stage, draining the ring); the asm reads are
+    // ordered by our own protocol instead (counted vmcnt + barrier above, lgkmcnt waits tied to the destinations below).
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned offA[C::CH / 2][2], offW[C::CH / 2][2];
+#pragma unroll
+    for (int s = 0; s < C::CH / 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ra_ = wr * 64 + i * 32 + r32, rw_ = wc * 64 + i * 32 + r32;
+            offA[s][i] = lds0 + ra_ * C::ROWB + swz<C>(ra_, 2 * s + h);
+            offW[s][i] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
+        }
+    auto compute = [&](int buf) {
+        const unsigned bo = buf * C::STAGE_BYTES;
+        u32x4 fa[C::CH / 2][2], fb[C::CH / 2][2];
+#pragma unroll
+        for (int s = 0; s < C::CH / 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][i]) : "v"(offA[s][i] + bo));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][j]) : "v"(offW[s][j] + bo));
+        }
+#pragma unroll
+        for (int s = 0; s < C::CH / 2; ++s) {
+            // reads return in order: all but the (CH/2 - 1 - s) * 4 youngest have landed
+            if (s == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]));
+            if (s == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
+            if (s == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fb[2][0]), "+v"(fb[2][1]));
+            if (s == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb[3][0]), "+v"(fb[3][1]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint4 av = make_uint4(fa[s][i].x, fa[s][i].y, fa[s][i].z, fa[s][i].w);
+                    const uint4 bv = make_uint4(fb[s][j].x, fb[s][j].y, fb[s][j].z, fb[s][j].w);
+                    mma_chunk<T>(av, bv, acc[i][j]);
+                }
+            __builtin_amdgcn_sched_barrier(0);      // keep step s's MFMAs ahead of step s+1's wait
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < n) issue(st_begin + d, d);
+    int buf = 0, nbuf = D % C::NBUF;              // buffer of stage i / of stage i + D
+    for (int i = 0; i < n; ++i) {
+        if (i + D <= n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + D < n) issue(st_begin + i + D, nbuf);
+        compute(buf);
+        buf = buf + 1 == C::NBUF ? 0 : buf + 1;
+        nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
+    }
+
+    if (SPLITK) {
+        float* slab = p.ws + (size_t)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nn = col0 + wc * 64 + j * 32 + r32;
+                if (nn >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                    if (m < p.M) slab[(size_t)m * p.N + nn] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    T* Cc = (T*)p.C;
+    const T* bias = (const T*)p.bias;
+    const T* res = (const T*)p.res;
+    if (EPI == EPI_SWIGLU) {
+        const int n_out = ((col0 + wc * 64) >> 1) + r32;
+        const bool ok_n = (col0 + wc * 64 + 32 + r32) < p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][0][r]) * acc[i][1][r]);
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = col0 + wc * 64 + j * 32 + r32;
+            if (nn >= p.N) continue;
+            const float bv = bias ? to_f32(bias[nn]) : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                float v = epi_act<T, EPI>(acc[i][j][r] + bv);
+                if (res) {
+                    const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+                    v += to_f32(res[(size_t)rr * p.ldr + nn]);
+                }
+                Cc[(size_t)m * p.ldc + nn] = from_f32<T>(v);
             }
         }
 }
@@ -260,16 +484,23 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(tiles * nsplit), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+    if (a.zeros && !(a.force_cfg & 0x2000))
+        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(tiles * nsplit), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(tiles * nsplit), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
 }
 
 template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return;
+    if (a.force_cfg & 0x4000) a.w_tiled = 1;        // timing experiments only
     constexpr int EPC = Elt<T>::PER_CHUNK;
-    // large M: 128x128 tiles (>= 2 waves of workgroups over 256 CUs); otherwise 256-row tiles so a weight panel is
-    // streamed by as few row tiles as possible (M <= 256: exactly once), with split-K filling the chip
-    const int tiles256_ = ((a.M + 255) / 256) * ((a.N + 127) / 128);
-    if ((tiles256_ >= 512 && a.force_split == 0) || a.force_cfg == 128) {
+    // Tile choice (measured on MI355X, tools/kbench.py):
+    //   M <= 256            -> 256x128 tiles + split-K: one row tile, every weight byte staged once
+    //   M  > 256, >= 96 tiles of 128x128 -> 128x128 tiles, no split (2 workgroups per CU overlap each other's phases)
+    //   otherwise (few tiles, long K: ViT fc2, o/down at T = 376) -> 256x128 tiles + split-K
+    const int tiles128_ = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool want128 = a.M > 256 && tiles128_ >= 96;
+    if ((want128 && a.force_split == 0) || (a.force_cfg & 0xFFF) == 128) {
         a.nsplit = 1;
         launch_cfg<T, EPI, Cfg128, false>(s, a, 1);
         return;
@@ -313,6 +544,9 @@ template <typename T, int EPI> static void gemm_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, Cfg128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg128::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, Cfg256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg256::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, Cfg256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg256::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128::NBUF * Cfg128::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
 }
 void gemm_init_attrs() {
     gemm_attr<bf16, EPI_NONE>(); gemm_attr<bf16, EPI_GELU_TANH>(); gemm_attr<bf16, EPI_GELU_ERF>(); gemm_attr<bf16, EPI_SWIGLU>();

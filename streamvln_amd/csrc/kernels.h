@@ -22,7 +22,9 @@ struct GemmArgs {
     int epi;
     float* ws; size_t ws_elems;   // split-K slab workspace (fp32) or null
     int nsplit;                   // filled by the launcher
-    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 128 -> 128x128 tiles; force_split S -> 256x128 tiles, S splits
+    const void* zeros;            // >= 16 B of zeros in device memory (K-tail source of the LDS-DMA path); null -> register-staged kernel
+    int w_tiled;                  // W is stored as [N/128][K stages][128 rows][128 B] (weight panel of a stage contiguous)
+    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a);
 
@@ -65,6 +67,13 @@ struct AttnArgs {
     int nsplit, tiles_per_split;  // split-KV: gridDim.z = nsplit, partials in `part`
     float* part;                  // [nsplit][n_kv_total][rows_pad][HD + 2] fp32 (O unnormalised, m, l)
     int rows_pad;
+    // decode fusion (T == 1, head_dim 128, one wave per workgroup): Q points at the UN-roped qkv row
+    // [(nq + 2 nkv) * 128]; the kernel applies RoPE to q in registers, and the workgroup that owns the page of
+    // position *dyn_pos ropes k, appends k / v to the pools (global) and patches its LDS tiles.
+    int fuse_rope_append;
+    const float* rope_tab;        // [max_positions][128]: cos[64] | sin[64]
+    const int* dyn_pos;
+    int nq_heads;
 };
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves);
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);
@@ -79,11 +88,12 @@ struct RopeKvArgs {
     void* qkv; int ld;
     void* Kpool; void* Vpool;
     const int* page_table;
-    const float* inv_freq;        // [64]
+    const float* rope_tab;        // [max_positions][128]: cos[64] | sin[64]  (launch_rope_table)
     int T, nq, nkv, P;
     const int* dyn_pos;
 };
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a);
+void launch_rope_table(hipStream_t s, float* tab, const float* inv_freq, int positions);
 
 // ViT: qkv [F*S][3*Hv] -> K pages [page][F*heads][64][HDP], Vt pages [page][F*heads][96][64]
 template <typename T> void launch_vit_kv_pack(hipStream_t s, const void* qkv, int ld, void* Kpool, void* Vpool, int F, int S,

@@ -87,8 +87,7 @@ __global__ __launch_bounds__(64) void rope_kv_kernel(RopeKvArgs p) {
     const float x1 = to_f32(row[d]), x2 = to_f32(row[d + 64]);
     const int page = p.page_table[pos >> 6], off = pos & 63;
     if (hd < p.nq + p.nkv) {
-        const float ang = (float)pos * p.inv_freq[d];
-        const float c = cosf(ang), s = sinf(ang);
+        const float c = p.rope_tab[(size_t)pos * 128 + d], s = p.rope_tab[(size_t)pos * 128 + 64 + d];
         const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;     // q*cos + rotate_half(q)*sin
         if (hd < p.nq) {
             row[d] = from_f32<T>(o1);
@@ -105,6 +104,14 @@ __global__ __launch_bounds__(64) void rope_kv_kernel(RopeKvArgs p) {
         vt[(size_t)d * 64 + off] = from_f32<T>(x1);
         vt[(size_t)(d + 64) * 64 + off] = from_f32<T>(x2);
     }
+}
+
+// cos/sin of pos * inv_freq[d] in fp32 (Qwen2RotaryEmbedding, modeling_qwen2.py:119-131), tabulated once
+__global__ __launch_bounds__(64) void rope_table_kernel(float* tab, const float* inv_freq, int positions) {
+    const int pos = blockIdx.x, d = threadIdx.x;
+    const float ang = (float)pos * inv_freq[d];
+    tab[(size_t)pos * 128 + d] = cosf(ang);
+    tab[(size_t)pos * 128 + 64 + d] = sinf(ang);
 }
 
 // ViT K/V packing: qkv [F*S][3*Hv] -> K pages [tile][F*heads][64][HDP] (zero padded), Vt [tile][F*heads][VROWS][64]
@@ -233,6 +240,9 @@ template <typename T> void launch_layernorm(hipStream_t s, const void* x, const 
 }
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a) {
     hipLaunchKernelGGL((rope_kv_kernel<T>), dim3(a.T, a.nq + 2 * a.nkv), dim3(64), 0, s, a);
+}
+void launch_rope_table(hipStream_t s, float* tab, const float* inv_freq, int positions) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3(positions), dim3(64), 0, s, tab, inv_freq, positions);
 }
 template <typename T> void launch_vit_kv_pack(hipStream_t s, const void* qkv, int ld, void* Kpool, void* Vpool, int F, int S, int heads,
                                              int head_dim) {

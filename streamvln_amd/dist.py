@@ -51,6 +51,7 @@ def init_distributed_mode(backend: str | None = None, timeout_s: int = 7200, qui
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_PORT", "29500")
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank,
                                 timeout=datetime.timedelta(seconds=timeout_s))
