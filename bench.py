@@ -183,8 +183,12 @@ def main():
         if n.value:
             avg_s = ms.value / n.value / 1e3
             ach = by.value / avg_s / 1e9
+            traffic = None          # HBM bytes/launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
+            pmc = os.path.join(ROOT, "profiles", "r01_gemv_swiglu_pmc.json")
+            if os.path.exists(pmc) and a.config == "streamvln_qwen2_7b" and a.dtype == "bf16":
+                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)", "achieved": round(ach, 1),
-                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                     "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
     # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
     summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
