@@ -58,10 +58,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
     const int wr = wave / C::WN, wc = wave % C::WN;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int tiles_n = (p.N + C::BN - 1) / C::BN;
     const int tiles_m = (p.M + C::BM - 1) / C::BM;
     const int nsplit = SPLITK ? p.nsplit : 1;
-    const int nwg = tiles_m * tiles_n * nsplit;
+    const int nwg = p.launch_tiles * nsplit;            // p.launch_tiles = (row tiles) x (column tiles of THIS launch)
     int bid = blockIdx.x;
     {   // XCD-aware bijective remap (blocks b, b+8, ... share an XCD): give each XCD a contiguous band
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
     // order: row tile fastest (they share the W panel), then K split, then column tile
     const int bm = bid % tiles_m;
     const int ks = (bid / tiles_m) % nsplit;
-    const int bn = bid / (tiles_m * nsplit);
+    const int bn = p.tile_base + bid / (tiles_m * nsplit);
     const int row0 = bm * C::BM, col0 = bn * C::BN;
     const int kchunks = p.K / EPC;
     const int stages_total = (kchunks + C::CH - 1) / C::CH;
@@ -263,10 +262,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     const int wr = wave / C::WN, wc = wave % C::WN;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int tiles_n = (p.N + C::BN - 1) / C::BN;
     const int tiles_m = (p.M + C::BM - 1) / C::BM;
     const int nsplit = SPLITK ? p.nsplit : 1;
-    const int nwg = tiles_m * tiles_n * nsplit;
+    const int nwg = p.launch_tiles * nsplit;            // p.launch_tiles = (row tiles) x (column tiles of THIS launch)
     int bid = blockIdx.x;
     {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -274,7 +272,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     }
     const int bm = bid % tiles_m;
     const int ks = (bid / tiles_m) % nsplit;
-    const int bn = bid / (tiles_m * nsplit);
+    const int bn = p.tile_base + bid / (tiles_m * nsplit);
     const int row0 = bm * C::BM, col0 = bn * C::BN;
     const int kchunks = p.K / EPC;
     const int stages_total = (kchunks + C::CH - 1) / C::CH;
@@ -431,14 +429,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
     const int n_out_total = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
-    const int quads = (n_out_total + 3) / 4;
+    // this launch covers output columns [n_out_begin, n_out_total) (tail launches start past column 0)
+    const int n_out_begin = EPI == EPI_SWIGLU ? p.tile_base * (Cfg256::BN / 2) : p.tile_base * Cfg256::BN;
+    const int quads = (n_out_total - n_out_begin + 3) / 4;
     const size_t total = (size_t)p.M * quads;
     const size_t slab = (size_t)p.M * p.N;
     T* Cc = (T*)p.C;
     const T* bias = (const T*)p.bias;
     const T* res = (const T*)p.res;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / quads), n0 = (int)(idx % quads) * 4;
+        const int m = (int)(idx / quads), n0 = n_out_begin + (int)(idx % quads) * 4;
         float out[4];
         if (EPI == EPI_SWIGLU) {
             // output j lives in packed columns (j/32)*64 + j%32 (gate) and +32 (up); 4 consecutive j share a block
@@ -483,49 +483,78 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 }
 
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
-    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    const int wgs = a.launch_tiles * nsplit;
+    if (wgs <= 0) return;
     if (a.zeros && !(a.force_cfg & 0x2000))
-        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(tiles * nsplit), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(tiles * nsplit), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+}
+
+template <typename T, int EPI> void launch_split(hipStream_t s, GemmArgs a, int S) {
+    a.nsplit = S;
+    launch_cfg<T, EPI, Cfg256, true>(s, a, S);
+    const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
+    const int n_begin = EPI == EPI_SWIGLU ? a.tile_base * (Cfg256::BN / 2) : a.tile_base * Cfg256::BN;
+    const size_t work = (size_t)a.M * ((n_out - n_begin) / 4 + 1);
+    int grid = (int)((work + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, a);
 }
 
 template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return;
     if (a.force_cfg & 0x4000) a.w_tiled = 1;        // timing experiments only
     constexpr int EPC = Elt<T>::PER_CHUNK;
+    a.tile_base = 0;
     // Tile choice (measured on MI355X, tools/kbench.py):
     //   M <= 256            -> 256x128 tiles + split-K: one row tile, every weight byte staged once
     //   M  > 256, >= 96 tiles of 128x128 -> 128x128 tiles, no split (2 workgroups per CU overlap each other's phases)
     //   otherwise (few tiles, long K: ViT fc2, o/down at T = 376) -> 256x128 tiles + split-K
-    const int tiles128_ = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const bool want128 = a.M > 256 && tiles128_ >= 96;
+    const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool want128 = a.M > 256 && tiles128 >= 96;
     if ((want128 && a.force_split == 0) || (a.force_cfg & 0xFFF) == 128) {
         a.nsplit = 1;
+        a.launch_tiles = tiles128;
         launch_cfg<T, EPI, Cfg128, false>(s, a, 1);
         return;
     }
-    const int tiles256 = ((a.M + 255) / 256) * ((a.N + 127) / 128);
+    // 256x128 tiles: ONE workgroup is resident per CU (144 KiB LDS ring), so workgroup counts are quantised in rounds
+    // of 256.  Pick the K split that fills one round (tiles * S <= 256); when a single row tile has between 256 and 512
+    // column tiles (gate/up at T <= 256: 296), run the first 256 tiles unsplit and the tail tiles K-split in a second
+    // launch instead of a nearly empty second round.
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 127) / 128;
+    const int tiles256 = tiles_m * tiles_n;
     const int stages = (a.K / EPC + Cfg256::CH - 1) / Cfg256::CH;
-    int S = 448 / tiles256;            // aim for >= ~1.5 workgroups per CU; never split when one wave of tiles fills the chip
-    if (S < 1) S = 1;
-    if (S > stages / 4) S = stages / 4;
-    if (S > 16) S = 16;
-    if (a.ws == nullptr) S = 1;
-    while (S > 1 && (size_t)S * a.M * a.N > a.ws_elems) --S;
-    if (a.N % 4 != 0 || (EPI == EPI_SWIGLU && a.N % 64 != 0)) S = 1;
-    if (a.force_split > 0) S = a.force_split;
-    if (S <= 1) {
-        a.nsplit = 1;
-        launch_cfg<T, EPI, Cfg256, false>(s, a, 1);
+    const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
+    auto pick = [&](int tiles) {
+        int S = 256 / tiles;
+        if (S < 1) S = 1;
+        if (S > stages / 2) S = stages / 2 < 1 ? 1 : stages / 2;
+        if (S > 16) S = 16;
+        if (!can_split) S = 1;
+        while (S > 1 && (size_t)S * a.M * a.N > a.ws_elems) --S;
+        return S;
+    };
+    if (a.force_split > 0) {
+        a.launch_tiles = tiles256;
+        if (a.force_split == 1) { a.nsplit = 1; launch_cfg<T, EPI, Cfg256, false>(s, a, 1); }
+        else launch_split<T, EPI>(s, a, a.force_split);
         return;
     }
-    a.nsplit = S;
-    launch_cfg<T, EPI, Cfg256, true>(s, a, S);
-    const size_t work = (size_t)a.M * ((EPI == EPI_SWIGLU ? a.N / 2 : a.N) / 4 + 1);
-    int grid = (int)((work + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, a);
+    if (tiles_m == 1 && tiles_n > 256 && tiles_n < 512 && can_split && pick(tiles_n - 256) > 1) {
+        a.nsplit = 1;
+        a.launch_tiles = 256;
+        launch_cfg<T, EPI, Cfg256, false>(s, a, 1);
+        a.tile_base = 256;
+        a.launch_tiles = tiles_n - 256;
+        launch_split<T, EPI>(s, a, pick(tiles_n - 256));
+        return;
+    }
+    a.launch_tiles = tiles256;
+    const int S = pick(tiles256);
+    if (S <= 1) { a.nsplit = 1; launch_cfg<T, EPI, Cfg256, false>(s, a, 1); }
+    else launch_split<T, EPI>(s, a, S);
 }
 
 }  // namespace

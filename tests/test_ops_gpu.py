@@ -96,6 +96,30 @@ def test_gemm_swiglu_and_posmod(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tail_tiles(dtype):
+    """one row tile, 296 column tiles (gate/up at T <= 256): first 256 tiles unsplit + K-split tail launch"""
+    m = engine(TINY, dtype)
+    M, I, K = 70, 18944, 256
+    A = q(rnd((M, K), 61), dtype)
+    gate, up = q(rnd((I, K), 62, 0.1), dtype), q(rnd((I, K), 63, 0.1), dtype)
+    packed = torch.zeros((2 * I, K))
+    idx = torch.arange(I)
+    packed[(idx // 32) * 64 + idx % 32] = gate
+    packed[(idx // 32) * 64 + 32 + idx % 32] = up
+    dA, dW = A.to(dtype).cuda(), packed.to(dtype).cuda()
+    out = torch.zeros((M, I), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU, 0, 0))
+    assert_close(out, O.silu(A @ gate.t()) * (A @ up.t()), dtype, "gemm swiglu tail tiles")
+    b, r = q(rnd((2 * I,), 64, 0.1), dtype), q(rnd((M, 2 * I), 65), dtype)
+    out2 = torch.zeros((M, 2 * I), dtype=dtype, device="cuda")
+    db, dr = b.to(dtype).cuda(), r.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out2), 2 * I, ptr(db), ptr(dr), 2 * I, 0, M, 2 * I, K, _lib.EPI_NONE, 0, 0))
+    assert_close(out2, A @ packed.t() + b + r, dtype, "gemm bias+res tail tiles")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,K,norm,bias,res", [(4608, 3584, True, True, False), (3584, 18944, False, False, True),
                                                (515, 512, True, False, True), (7, 64, False, True, False)])
 def test_gemv(dtype, N, K, norm, bias, res):
