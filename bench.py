@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-feature-cache-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
@@ -68,6 +69,8 @@ class Runner:
                                     preprocess=lambda idx: self.frames[idx])
         self.step = 0
         self.actions = 0
+        self.model = model
+        self.cache_frames = 0
 
     def turn(self):
         """run env steps until one model turn has happened"""
@@ -76,6 +79,8 @@ class Runner:
             if self.step == EP_STEPS:                       # next episode
                 self.agent.reset_memory()
                 self.step = 0
+                if self.cache_frames:                       # a new episode brings new frames: start from an empty cache
+                    self.model.set_feature_cache(self.cache_frames)
             self.agent.act(self.step)
             self.step += 1
             self.actions += 1
@@ -190,6 +195,35 @@ def main():
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)", "achieved": round(ach, 1),
                     "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                     "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
+    # second pass: opt-in frame-feature memoisation.  Reported separately; `value` above re-encodes the
+    # history frames at every window restart exactly as the reference does.
+    cached = None
+    if not a.no_feature_cache_pass:
+        run.cache_frames = 96
+        model.set_feature_cache(96)
+        while run.step <= EP_STEPS - NUM_FUTURE:    # finish the current episode so the pass starts on an episode boundary
+            run.turn()                              # (after the last turn of an episode run.step == EP_STEPS - NUM_FUTURE + 1)
+        for _ in range(a.warmup):
+            run.turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0c = time.perf_counter()
+        for _ in range(a.steps):
+            run.turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtc = time.perf_counter() - t0c
+        if world > 1:
+            tt = torch.tensor([dtc], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtc = float(tt.item())
+        hits, misses = model.feature_cache_stats()
+        cached = {"value": round(NUM_FUTURE * a.steps * world / dtc, 2), "ms_per_step": round(dtc / a.steps * 1e3, 3),
+                  "hits": hits, "misses": misses,
+                  "note": "opt-in: pooled features of frames already encoded in the episode are reused (content hash) instead of "
+                          "re-running the ViT on the 8 <memory> frames; not the headline value"}
     # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
     summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     turns_total = a.steps * world
@@ -209,6 +243,7 @@ def main():
                                   "decode": round(d3[2].value / a.steps, 3)},
             "metric_allreduce_check": summary,
             "roofline": roof,
+            "with_feature_cache": cached,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(CONFIGS["streamvln_qwen2_7b"])

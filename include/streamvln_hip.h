@@ -83,6 +83,13 @@ int svln_probe_reset(svln_engine* h);
 int svln_probe_read(svln_engine* h, double* total_ms, int64_t* launches, double* bytes_per_launch);
 int svln_phase_times(svln_engine* h, double* vision_ms, double* prefill_ms, double* decode_ms, int reset);
 
+/* -- optional memoisation of pooled frame features keyed by a 128-bit content hash of the pixels:
+ * the <memory> frames of a window restart were all encoded earlier as "current" frames, so with the cache on they
+ * skip the ViT.  capacity_frames = 0 (default) disables it: every frame is re-encoded, as the reference does
+ * (stream_video_vln.py:104). */
+int svln_set_feature_cache(svln_engine* h, int capacity_frames);
+int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses);
+
 /* -- single-kernel entry points (device pointers in the engine dtype) for the op-level parity tests */
 /* force_cfg: 0 = heuristic, 128 = 128x128 tiles; force_split: 0 = heuristic, S >= 1 = 256x128 tiles with S K-splits */
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res,

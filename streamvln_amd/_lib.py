@@ -53,6 +53,8 @@ SIGNATURES = {
     "svln_probe_reset": (_I, [_P]),
     "svln_probe_read": (_I, [_P, _PD, _PI64, _PD]),
     "svln_phase_times": (_I, [_P, _PD, _PD, _PD, _I]),
+    "svln_set_feature_cache": (_I, [_P, _I]),
+    "svln_feature_cache_stats": (_I, [_P, _PI64, _PI64]),
     "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
     "svln_op_rmsnorm": (_I, [_P, _P, _P, _P, _I, _I, _F]),

@@ -65,6 +65,8 @@ struct EngineBase {
     virtual void probe_reset() = 0;
     virtual void probe_read(double* ms, int64_t* launches, double* bytes) = 0;
     virtual void phase_times(double* v, double* p, double* d, int reset) = 0;
+    virtual void set_feature_cache(int cap) = 0;
+    virtual void feature_cache_stats(int64_t* hits, int64_t* misses) = 0;
     virtual void op_gemm(const GemmArgs& a) = 0;
     virtual void op_gemv(GemvArgs a, int32_t* host_token) = 0;
     virtual void op_rmsnorm(const void* x, const void* g, void* y, int rows, int n, float eps) = 0;
@@ -289,6 +291,7 @@ public:
         for (auto e : probe_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
         (void)hipHostFree(h_dyn);
+        if (h_hash) (void)hipHostFree(h_hash);
         for (void* p : allocs) (void)hipFree(p);
         (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
         (void)hipStreamDestroy(st);
@@ -389,15 +392,11 @@ public:
         launch_attention<T>(st, a, vhd, 4);
         if (a.nsplit > 1) launch_attention_combine<T>(st, a, vhd);
     }
-    void encode_frames(const float* pixels, int F, int on_device) override {
-        REQUIRE(F >= 1 && F <= c.max_frames, "n_frames out of range");
-        REQUIRE(weights_missing() == 0, g_err);
-        const size_t pbytes = (size_t)F * 3 * c.v_image * c.v_image * sizeof(float);
-        HIP_CHECK(hipEventRecord(ph_ev[0], st));
-        HIP_CHECK(hipMemcpyAsync(pix, pixels, pbytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    // SigLIP tower + projector + pool on F frames of `pixbuf` (fp32 [F,3,S,S]) -> dst [F*otok][H]
+    void run_vit(const float* pixbuf, int F, T* dst) {
         const int M = F * S;
         // SigLipVisionEmbeddings (siglip_encoder.py:169-174): patch GEMM + bias + position embedding
-        launch_patchify<T>(st, pix, patches, F, c.v_image, c.v_patch, kp);
+        launch_patchify<T>(st, pixbuf, patches, F, c.v_image, c.v_patch, kp);
         launch_gemm<T>(st, gemm_args(patches, kp, patch_w, kp, vx, Hv, patch_b, pos_emb, Hv, S, M, Hv, kp, EPI_NONE));
         for (int i = 0; i < c.v_layers; ++i) {      // SigLipEncoderLayer (siglip_encoder.py:269-305)
             const VLayer& L = vl[i];
@@ -412,7 +411,83 @@ public:
         // mm_projector (builder.py:41-48) then get_2dPool bilinear 27x27 -> 14x14 (stream_video_vln.py:53-73)
         launch_gemm<T>(st, gemm_args(vx, Hv, proj0_w, Hv, proj_h, H, proj0_b, nullptr, 0, 0, M, H, Hv, EPI_GELU_ERF));
         launch_gemm<T>(st, gemm_args(proj_h, H, proj2_w, H, proj_o, H, proj2_b, nullptr, 0, 0, M, H, H, EPI_NONE));
-        launch_pool<T>(st, proj_o, feats, tap_idx, tap_w, F, side, oside, H);
+        launch_pool<T>(st, proj_o, dst, tap_idx, tap_w, F, side, oside, H);
+    }
+
+    // Optional memoisation of pooled frame features: the reference re-encodes the
+    // num_history memory frames through the ViT at every window restart (stream_video_vln.py:104); the same pixels through
+    // the same frozen weights give the same features, so frames are keyed by a 128-bit content hash and reused.  OFF by
+    // default (svln_set_feature_cache).
+    struct CacheEntry { unsigned long long a, b; uint64_t stamp; bool used; };
+    int fc_cap = 0; T* fc_store = nullptr; std::vector<CacheEntry> fc_entries; uint64_t fc_clock = 0;
+    int64_t fc_hits = 0, fc_misses = 0;
+    float* pix2 = nullptr; T* feats_stage = nullptr; unsigned long long* d_hash = nullptr; unsigned long long* h_hash = nullptr;
+    void set_feature_cache(int cap) override {
+        REQUIRE(cap >= 0, "capacity must be >= 0");
+        if (cap > 0 && cap != (int)fc_entries.size()) {
+            REQUIRE(fc_store == nullptr, "feature cache capacity can be set once");
+            fc_store = dalloc<T>((size_t)cap * otok * H);
+            fc_entries.assign(cap, CacheEntry{0, 0, 0, false});
+            pix2 = dalloc<float>((size_t)c.max_frames * 3 * c.v_image * c.v_image);
+            feats_stage = dalloc<T>((size_t)c.max_frames * otok * H);
+            d_hash = dalloc<unsigned long long>(2 * c.max_frames);
+            HIP_CHECK(hipHostMalloc((void**)&h_hash, 2 * c.max_frames * sizeof(unsigned long long)));
+        }
+        fc_cap = cap;
+        for (auto& e : fc_entries) e.used = false;
+    }
+    void feature_cache_stats(int64_t* hits, int64_t* misses) override { *hits = fc_hits; *misses = fc_misses; }
+
+    void encode_frames(const float* pixels, int F, int on_device) override {
+        REQUIRE(F >= 1 && F <= c.max_frames, "n_frames out of range");
+        REQUIRE(weights_missing() == 0, g_err);
+        const size_t fwords = (size_t)3 * c.v_image * c.v_image;
+        HIP_CHECK(hipEventRecord(ph_ev[0], st));
+        HIP_CHECK(hipMemcpyAsync(pix, pixels, F * fwords * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (fc_cap <= 0) {
+            run_vit(pix, F, feats);
+        } else {
+            HIP_CHECK(hipMemsetAsync(d_hash, 0, 2 * F * sizeof(unsigned long long), st));
+            launch_frame_hash(st, pix, F, fwords, d_hash);
+            HIP_CHECK(hipMemcpyAsync(h_hash, d_hash, 2 * F * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            std::vector<int> slot(F, -1), miss;
+            for (int f = 0; f < F; ++f) {
+                for (int k = 0; k < fc_cap; ++k)
+                    if (fc_entries[k].used && fc_entries[k].a == h_hash[2 * f] && fc_entries[k].b == h_hash[2 * f + 1]) { slot[f] = k; break; }
+                if (slot[f] >= 0) { fc_entries[slot[f]].stamp = ++fc_clock; ++fc_hits; }
+                else { miss.push_back(f); ++fc_misses; }
+            }
+            const size_t fbytes = (size_t)otok * H * sizeof(T);
+            if (!miss.empty()) {
+                for (size_t j = 0; j < miss.size(); ++j)
+                    HIP_CHECK(hipMemcpyAsync(pix2 + j * fwords, pix + (size_t)miss[j] * fwords, fwords * sizeof(float), hipMemcpyDeviceToDevice, st));
+                run_vit(pix2, (int)miss.size(), feats_stage);
+                for (size_t j = 0; j < miss.size(); ++j) {
+                    const int f = miss[j];
+                    int victim = -1;                                           // free slot, else least recently used
+                    for (int k = 0; k < fc_cap; ++k) {
+                        bool taken = false;
+                        for (int g = 0; g < F; ++g) taken |= slot[g] == k;     // never evict a slot this call still needs
+                        if (taken) continue;
+                        if (!fc_entries[k].used) { victim = k; break; }
+                        if (victim < 0 || fc_entries[k].stamp < fc_entries[victim].stamp) victim = k;
+                    }
+                    HIP_CHECK(hipMemcpyAsync((char*)feats + (size_t)f * fbytes, (char*)feats_stage + j * fbytes, fbytes, hipMemcpyDeviceToDevice, st));
+                    if (victim >= 0) {
+                        HIP_CHECK(hipMemcpyAsync((char*)fc_store + (size_t)victim * fbytes, (char*)feats_stage + j * fbytes, fbytes, hipMemcpyDeviceToDevice, st));
+                        fc_entries[victim] = CacheEntry{h_hash[2 * f], h_hash[2 * f + 1], ++fc_clock, true};
+                        slot[f] = victim;
+                    }
+                }
+            }
+            for (int f = 0; f < F; ++f) {
+                bool was_miss = false;
+                for (int g : miss) was_miss |= g == f;
+                if (!was_miss)
+                    HIP_CHECK(hipMemcpyAsync((char*)feats + (size_t)f * fbytes, (char*)fc_store + (size_t)slot[f] * fbytes, fbytes, hipMemcpyDeviceToDevice, st));
+            }
+        }
         HIP_CHECK(hipEventRecord(ph_ev[1], st));
         vision_pending = true;
         n_feat_frames = F;
@@ -785,6 +860,8 @@ int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN h->impl->set_g
 int svln_probe_reset(svln_engine* h) { API_BEGIN h->impl->probe_reset(); API_END }
 int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN h->impl->probe_read(ms, launches, bytes); API_END }
 int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN h->impl->phase_times(v, p, d, reset); API_END }
+int svln_set_feature_cache(svln_engine* h, int capacity_frames) { API_BEGIN h->impl->set_feature_cache(capacity_frames); API_END }
+int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses) { API_BEGIN h->impl->feature_cache_stats(hits, misses); API_END }
 
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                  int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split) {

@@ -94,6 +94,8 @@ struct RopeKvArgs {
 };
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a);
 void launch_rope_table(hipStream_t s, float* tab, const float* inv_freq, int positions);
+// out[2f], out[2f+1] += 128-bit content key of frame f (caller zeroes `out` first)
+void launch_frame_hash(hipStream_t s, const float* pix, int F, size_t words_per_frame, unsigned long long* out);
 
 // ViT: qkv [F*S][3*Hv] -> K pages [page][F*heads][64][HDP], Vt pages [page][F*heads][96][64]
 template <typename T> void launch_vit_kv_pack(hipStream_t s, const void* qkv, int ld, void* Kpool, void* Vpool, int F, int S,

@@ -114,6 +114,21 @@ __global__ __launch_bounds__(64) void rope_table_kernel(float* tab, const float*
     tab[(size_t)pos * 128 + 64 + d] = sinf(ang);
 }
 
+// 128-bit content key of each frame: two position-dependent, order-independent 64-bit sums over the pixel words
+// (64-bit atomic adds of per-thread partial sums), used to memoise pooled frame features (engine feature cache).
+__global__ __launch_bounds__(256) void frame_hash_kernel(const uint32_t* pix, size_t words_per_frame, unsigned long long* out) {
+    const int f = blockIdx.y;
+    const uint32_t* p = pix + (size_t)f * words_per_frame;
+    unsigned long long a = 0, b = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words_per_frame; i += (size_t)gridDim.x * 256) {
+        const uint64_t v = (uint64_t)p[i] | ((uint64_t)i << 32);
+        a += splitmix64(v ^ 0x243F6A8885A308D3ull);
+        b += splitmix64(v * 0x9E3779B97F4A7C15ull + 0x13198A2E03707344ull);
+    }
+    atomicAdd(out + 2 * f, a);
+    atomicAdd(out + 2 * f + 1, b);
+}
+
 // ViT K/V packing: qkv [F*S][3*Hv] -> K pages [tile][F*heads][64][HDP] (zero padded), Vt [tile][F*heads][VROWS][64]
 template <typename T>
 __global__ __launch_bounds__(256) void vit_kv_pack_kernel(const T* qkv, int ld, T* Kpool, T* Vpool, int F, int S, int heads, int HD,
@@ -240,6 +255,9 @@ template <typename T> void launch_layernorm(hipStream_t s, const void* x, const 
 }
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a) {
     hipLaunchKernelGGL((rope_kv_kernel<T>), dim3(a.T, a.nq + 2 * a.nkv), dim3(64), 0, s, a);
+}
+void launch_frame_hash(hipStream_t s, const float* pix, int F, size_t words_per_frame, unsigned long long* out) {
+    hipLaunchKernelGGL(frame_hash_kernel, dim3(64, F), dim3(256), 0, s, (const uint32_t*)pix, words_per_frame, out);
 }
 void launch_rope_table(hipStream_t s, float* tab, const float* inv_freq, int positions) {
     hipLaunchKernelGGL(rope_table_kernel, dim3(positions), dim3(64), 0, s, tab, inv_freq, positions);

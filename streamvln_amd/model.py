@@ -312,6 +312,15 @@ class StreamVLNForCausalLM:
         _check(self._lib.svln_get_embeds(self._h, env_id, start, n, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def set_feature_cache(self, capacity_frames: int):
+        """Memoise pooled frame features by pixel content (opt-in; 0 = re-encode every frame like the reference)."""
+        _check(self._lib.svln_set_feature_cache(self._h, int(capacity_frames)))
+
+    def feature_cache_stats(self):
+        hits, misses = C.c_int64(), C.c_int64()
+        _check(self._lib.svln_feature_cache_stats(self._h, C.byref(hits), C.byref(misses)))
+        return hits.value, misses.value
+
     def set_decode_graph(self, enable: bool):
         _check(self._lib.svln_set_decode_graph(self._h, int(enable)))
 

@@ -95,6 +95,22 @@ def test_bf16_mode_vs_golden(name):
     m.close()
 
 
+def test_feature_cache_keeps_parity_and_skips_history_reencode():
+    """opt-in memoisation of pooled frame features: same ids / hidden as the reference fixture, history frames hit"""
+    sc, g = SCENARIOS["tiny_episode"], load_golden("tiny_episode")
+    m = _model(sc, torch.float32)
+    m.set_feature_cache(32)
+    log, taps = _run(m, sc)
+    for t, rec in enumerate(log):
+        assert rec["out"].sequences[0].tolist() == g[f"t{t}_ids"].tolist(), t
+        assert np.abs(taps[t]["hidden"] - g[f"t{t}_hidden"]).max() <= HIDDEN_TOL, t
+    hits, misses = m.feature_cache_stats()
+    # frames seen: 9 turn frames + history {0, 6} at step 12 and {0, 12} at step 24 -> 13 lookups; 0, 0 and 12 are hits
+    assert hits == 3 and misses == 10, (hits, misses)
+    m.set_feature_cache(0)
+    m.close()
+
+
 def test_graph_replay_equals_plain_launches():
     sc = SCENARIOS["tiny_episode"]
     outs = []
