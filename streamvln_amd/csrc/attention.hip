@@ -35,6 +35,8 @@ template <typename T, int HD> struct AttnGeom {
     static constexpr bool KSWZ = (HDC % 16) == 0;
 };
 
+SVLN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32
+
 // K tile: chunk c of key row `row`
 template <typename G> SVLN_DEV int k_off(int row, int c) {
     return row * (G::HDC * 16) + ((G::KSWZ ? (c ^ (row & 15)) : c) << 4);
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
     const int kt_begin = blockIdx.z * p.tiles_per_split;
     const int kt_end = min(tiles, kt_begin + p.tiles_per_split);
 
+    const float scale2 = p.scale * 1.4426950408889634f;      // scores are kept in the log2 domain (m too)
     f32x16 O[G::DT];
 #pragma unroll
     for (int d = 0; d < G::DT; ++d)
@@ -123,13 +126,61 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
     const size_t k_page_stride = (size_t)p.n_kv_total * 64 * G::HDP * sizeof(T);
     const size_t v_page_stride = (size_t)p.n_kv_total * G::VROWS * 64 * sizeof(T);
 
+    // 4-wave workgroups (prefill / ViT): the next tile's K / Vt loads are issued into registers right after the barrier
+    // that publishes the current tile and stay in flight under its MFMAs (one tile of HBM/L2 latency hidden per tile).
+    constexpr bool PREFETCH = WAVES == 4;
+    constexpr int KTOT_ = 64 * G::HDC, VTOT_ = G::VROWS * G::VC;
+    constexpr int KLP = (KTOT_ + NT - 1) / NT, VLP = (VTOT_ + NT - 1) / NT;
+    uint4 pk[PREFETCH ? KLP : 1], pv[PREFETCH ? VLP : 1];
+    auto load_regs = [&](int kt) {
+        const int pg = kt == kt0 ? page0 : (p.page_table ? p.page_table[kt] : kt);
+        const char* gk = (const char*)p.Kpool + (size_t)pg * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
+        const char* gv = (const char*)p.Vpool + (size_t)pg * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
+#pragma unroll
+        for (int u = 0; u < KLP; ++u) {
+            const int q = tid + u * NT;
+            pk[u] = q < KTOT_ ? *(const uint4*)(gk + (size_t)q * 16) : zero_chunk();
+        }
+#pragma unroll
+        for (int u = 0; u < VLP; ++u) {
+            const int q = tid + u * NT;
+            pv[u] = q < VTOT_ ? *(const uint4*)(gv + (size_t)q * 16) : zero_chunk();
+        }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int u = 0; u < KLP; ++u) {
+            const int q = tid + u * NT;
+            if (q < KTOT_) {
+                const int row = q / G::HDC, c = q - row * G::HDC;
+                *(uint4*)(sK + k_off<G>(row, c)) = pk[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VLP; ++u) {
+            const int q = tid + u * NT;
+            if (q < VTOT_) {
+                const int row = q / G::VC, c = q - row * G::VC;
+                if (sizeof(T) == 4) {
+                    *(uint4*)(sV + v_off_f32(row, c)) = pv[u];
+                } else {
+                    *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(pv[u].x, pv[u].y);
+                    *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(pv[u].z, pv[u].w);
+                }
+            }
+        }
+    };
+    if (PREFETCH && kt_begin < kt_end) load_regs(kt_begin);
+
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int page = kt == kt0 ? page0 : (p.page_table ? p.page_table[kt] : kt);
         const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
         const char* gV = (const char*)p.Vpool + (size_t)page * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
         // ---- stage K and Vt tiles: coalesced 16-byte loads issued in batches (all in flight before the first
         //      dependent LDS write), swizzled LDS writes
-        {
+        if (PREFETCH) {
+            store_regs();
+        } else {
             constexpr int KTOT = 64 * G::HDC, VTOT = G::VROWS * G::VC, B = WAVES == 1 ? 4 : 8;
             constexpr int KL = (KTOT + NT - 1) / NT, VL = (VTOT + NT - 1) / NT;
 #pragma unroll
@@ -201,6 +252,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
+        if (PREFETCH && kt + 1 < kt_end) load_regs(kt + 1);
 
         // ---- S^T[j] = K_tile[j*32 .. j*32+31] . Q^T   (rows = keys, col = this lane's query)
         f32x16 S[2];
@@ -225,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int key = kt * 64 + j * 32 + acc_row(e, lane);
                 const bool ok = key < kv_len && (!p.causal || key <= qpos);
-                const float sv = ok ? S[j][e] * p.scale : -INFINITY;
+                const float sv = ok ? S[j][e] * scale2 : -INFINITY;        // log2 domain: softmax via v_exp_f32 (2^x)
                 S[j][e] = sv;
                 mloc = fmaxf(mloc, sv);
             }
@@ -238,12 +290,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) S[j][e] = 0.0f;
         } else {
-            alpha = expf(m - mnew);          // m = -inf -> 0
+            alpha = fast_exp2(m - mnew);     // m = -inf -> 0
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = expf(S[j][e] - mnew);
+                    const float pv = fast_exp2(S[j][e] - mnew);
                     S[j][e] = pv;
                     psum += pv;
                 }
@@ -376,6 +428,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
         }
     }
 
+    const float scale2 = p.scale * 1.4426950408889634f;
     f32x16 O;
 #pragma unroll
     for (int e = 0; e < 16; ++e) O[e] = 0.0f;
@@ -449,19 +502,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kt * 64 + j * 32 + acc_row(e, lane);
-                const float sv = key < kv_len ? S[j][e] * p.scale : -INFINITY;
+                const float sv = key < kv_len ? S[j][e] * scale2 : -INFINITY;
                 S[j][e] = sv;
                 mloc = fmaxf(mloc, sv);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);          // the first key of every processed tile is valid -> finite
-        const float alpha = expf(m - mnew);
+        const float alpha = fast_exp2(m - mnew);
         float psum = 0.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = expf(S[j][e] - mnew);
+                const float pv = fast_exp2(S[j][e] - mnew);
                 S[j][e] = pv;
                 psum += pv;
             }
@@ -517,7 +570,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
     float mz = -INFINITY, lz = 0.0f;
     if (lane < nsplit) { mz = base[lane * split_stride + HD]; lz = base[lane * split_stride + HD + 1]; }
     const float mstar = wave_max(mz);
-    const float w = mz == -INFINITY ? 0.0f : expf(mz - mstar);
+    const float w = mz == -INFINITY ? 0.0f : fast_exp2(mz - mstar);      // m values are in the log2 domain
     const float lsum = wave_sum(w * lz);
     wsh[lane] = w;
     __syncthreads();
