@@ -11,6 +11,8 @@
 // Roofline: HBM.  Algorithmic bytes per launch = N*K*sizeof(T) (+ x, y: negligible).
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -133,12 +135,11 @@ SVLN_DEV void dot_rows(const T* const (&rows)[R], const float* xs, const T* xg, 
 // Small-N variant (qkv / o / down projections of a decode step: N <= 8192 rows is only 224-288 workgroups of the
 // wave-per-rows kernel, i.e. < 1 per CU).  Here a workgroup owns 4 rows and its 4 waves split K (interleaved
 // 1 KiB blocks), so N/4 workgroups exist (3.5-4.5 per CU) and their prologues overlap other workgroups' streams.
-template <typename T, bool NORM>
+template <typename T, bool NORM, int R>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_ksplit_kernel(GemvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ float part[GEMV_WAVES][5];
+    __shared__ float part[GEMV_WAVES][R + 1];
     constexpr int EPC = Elt<T>::PER_CHUNK;
-    constexpr int R = 4;
     const int nch = p.K / EPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T* W = (const T*)p.W;
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_ksplit_kernel(GemvArgs p) {
             }
             acc[R] = wave_sum(acc[R]);
         } else {
-            float a4[R] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float a4[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a4[r] = 0.0f;
             dot_accum<T, R, false>(rows, nullptr, xg, nch, wave * 64, GEMV_WAVES, lane, a4);
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = a4[r];
@@ -308,6 +311,7 @@ int gemv_grid(int N) {
     const int groups = (N + 3) / 4;
     const int wg_groups = (groups + GEMV_WAVES - 1) / GEMV_WAVES;       // workgroup-iterations needed
     if (wg_groups <= 1280) return wg_groups < 1 ? 1 : wg_groups;
+    if (wg_groups > 4 * 1280) return 1024;          // many iterations per wave (lm_head): imbalance is negligible, 1024 measured best
     if (groups % GEMV_WAVES == 0)
         for (int g = 1280; g >= 640; --g)
             if (wg_groups % g == 0) return g;
@@ -325,10 +329,13 @@ template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a) { launc
 template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, hipEvent_t start, hipEvent_t stop) {
     dim3 b(GEMV_THREADS);
     if (a.epi == EPI_NONE && a.N <= 8192) {
-        int grid = (a.N + 3) / 4;
+        static const int r_env = getenv("SVLN_GEMV_R") ? atoi(getenv("SVLN_GEMV_R")) : 0;      // tuning experiments
+        const int R = r_env ? r_env : 2;
+        int grid = (a.N + R - 1) / R;
         if (grid > 2048) grid = 2048;
-        if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true>), dim3(grid), b, 0);
-        else SVLN_LAUNCH((gemv_ksplit_kernel<T, false>), dim3(grid), b, 0);
+        if (R == 2) { if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, 2>), dim3(grid), b, 0); else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, 2>), dim3(grid), b, 0); }
+        else if (R == 8) { if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, 8>), dim3(grid), b, 0); else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, 8>), dim3(grid), b, 0); }
+        else { if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, 4>), dim3(grid), b, 0); else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, 4>), dim3(grid), b, 0); }
         return;
     }
     const int grid = gemv_grid(a.N);
@@ -347,9 +354,7 @@ template void launch_gemv_timed<float>(hipStream_t, const GemvArgs&, hipEvent_t,
 template <typename T, int EPI> static void gemv_attr() {
     (void)hipFuncSetAttribute((const void*)gemv_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
-template <typename T> static void gemv_ksplit_attr() {
-    (void)hipFuncSetAttribute((const void*)gemv_ksplit_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-}
+template <typename T> static void gemv_ksplit_attr() {}
 void gemv_init_attrs() {
     gemv_ksplit_attr<bf16>(); gemv_ksplit_attr<float>();
     gemv_attr<bf16, EPI_NONE>(); gemv_attr<bf16, EPI_SWIGLU>(); gemv_attr<bf16, EPI_ARGMAX>();

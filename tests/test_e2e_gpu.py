@@ -144,3 +144,130 @@ def test_operator_surface_errors():
     with pytest.raises(ValueError):
         m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], past_key_values=out.past_key_values)   # stale handle
     m.close()
+
+
+def _first_turn_inputs(m, sc, step=0, n_text=24, seed=3):
+    from streamvln_amd.synthetic import synthetic_frame
+    rng = np.random.default_rng(seed)
+    ids = [int(t) for t in rng.integers(10, sc["cfg"].vocab, n_text)]
+    ids.insert(n_text - 2, -200)
+    img = m.get_vision_tower().image_processor.preprocess_array(synthetic_frame(0, step))[None, None].cuda()
+    return torch.tensor([ids]), img
+
+
+def test_two_envs_are_isolated():
+    """per-env state (embeds, KV pages): interleaving two envs gives each the outputs it has alone"""
+    sc = SCENARIOS["tiny_episode"]
+    m = StreamVLNForCausalLM(sc["cfg"], dtype=torch.float32, max_envs=2, max_frames=3, max_positions=2048)
+    m.load_synthetic(SEED)
+    m.model.num_history = 2
+    ids_a, img_a = _first_turn_inputs(m, sc, step=0, seed=3)
+    ids_b, img_b = _first_turn_inputs(m, sc, step=5, seed=4)
+
+    def two_turns(env, ids, img):
+        o1 = m.generate(inputs=ids, images=img, env_id=env, time_ids=[[0]], max_new_tokens=3, eos_token_ids=[])
+        ids2 = torch.cat([o1.sequences.cpu(), torch.tensor([[7, 8, -200, 9]])], 1)
+        o2 = m.generate(inputs=ids2, images=img, env_id=env, time_ids=[[0, 1, 2, 3, 4]], max_new_tokens=3, eos_token_ids=[],
+                        past_key_values=o1.past_key_values)
+        return o1.sequences[0].tolist() + o2.sequences[0].tolist(), m.last_hidden()
+    alone_a = two_turns(0, ids_a, img_a)
+    m.reset_for_env(0)
+    alone_b = two_turns(0, ids_b, img_b)
+    m.reset(2)
+    a1 = m.generate(inputs=ids_a, images=img_a, env_id=0, time_ids=[[0]], max_new_tokens=3, eos_token_ids=[])
+    b1 = m.generate(inputs=ids_b, images=img_b, env_id=1, time_ids=[[0]], max_new_tokens=3, eos_token_ids=[])
+    tail = torch.tensor([[7, 8, -200, 9]])
+    a2 = m.generate(inputs=torch.cat([a1.sequences.cpu(), tail], 1), images=img_a, env_id=0, time_ids=[[0, 1, 2, 3, 4]], max_new_tokens=3,
+                    eos_token_ids=[], past_key_values=a1.past_key_values)
+    ha = m.last_hidden()
+    b2 = m.generate(inputs=torch.cat([b1.sequences.cpu(), tail], 1), images=img_b, env_id=1, time_ids=[[0, 1, 2, 3, 4]], max_new_tokens=3,
+                    eos_token_ids=[], past_key_values=b1.past_key_values)
+    hb = m.last_hidden()
+    assert a1.sequences[0].tolist() + a2.sequences[0].tolist() == alone_a[0]
+    assert b1.sequences[0].tolist() + b2.sequences[0].tolist() == alone_b[0]
+    assert np.array_equal(ha, alone_a[1]) and np.array_equal(hb, alone_b[1])
+    with pytest.raises(ValueError):
+        m.generate(inputs=ids_a, images=img_a, env_id=1, time_ids=[[0]], past_key_values=a2.past_key_values)   # handle of another env
+    m.close()
+
+
+def test_sequence_limit_is_an_error_not_a_fault():
+    sc = SCENARIOS["tiny_episode"]
+    m = StreamVLNForCausalLM(sc["cfg"], dtype=torch.bfloat16, max_envs=1, max_frames=3, max_positions=256)
+    m.load_synthetic(SEED)
+    ids, img = _first_turn_inputs(m, sc)
+    out = m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=2, eos_token_ids=[])      # 24 + 196 rows fit
+    from streamvln_amd._lib import SvlnError
+    with pytest.raises(SvlnError):                                                                            # + 196 more do not
+        m.generate(inputs=torch.cat([out.sequences.cpu(), ids], 1), images=img, env_id=0, time_ids=[[0, 1, 2, 3, 4]], max_new_tokens=2,
+                   eos_token_ids=[], past_key_values=out.past_key_values)
+    m.reset_for_env(0)
+    out2 = m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=2, eos_token_ids=[])     # engine still usable
+    assert out2.sequences.tolist() == out.sequences.tolist()
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_path_equals_prefill_path(dtype):
+    """size-independent property at true dimensions: tokens produced by the decode path (GEMV + split-KV attention with the
+    fused RoPE/KV append, hipGraph replay) are reproduced by ONE prefill (MFMA GEMM + causal attention) over the same
+    embeddings: teacher-forced arg-max at the last position == last generated token; kv_reset re-prefill == first token."""
+    from streamvln_amd.config import TRUE1
+    import ctypes as C
+    sc = dict(SCENARIOS["true1_episode"])
+    m = StreamVLNForCausalLM(TRUE1, dtype=dtype, max_envs=1, max_frames=9, max_positions=4096)
+    m.load_synthetic(SEED)
+    m.model.num_history = 8
+    m.set_decode_graph(True)
+    ids, img = _first_turn_inputs(m, sc, n_text=180)
+    out = m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=5, eos_token_ids=[])
+    toks = out.sequences[0].tolist()
+    h_dec = m.last_hidden()
+    assert out.past_key_values.get_seq_length() == 180 + 196 + 5 - 1
+    lib, h = m._lib, m._h
+    from streamvln_amd import _lib
+
+    def regen(n_new):
+        o = np.zeros(n_new, dtype=np.int64)
+        n = C.c_int32()
+        _lib.check(lib.svln_generate(h, 0, n_new, None, 0, o.ctypes.data_as(C.POINTER(C.c_int64)), n_new, C.byref(n)))
+        return o[: n.value].tolist()
+    _lib.check(lib.svln_kv_reset(h, 0))                         # past_key_values=None: re-prefill everything accumulated
+    assert regen(1) == toks[:1]
+    fed = np.asarray(toks[:4], dtype=np.int64)                  # teacher forcing: embeds of t0..t3 appended, one prefill of L+4 rows
+    _lib.check(lib.svln_append_turn(h, 0, fed.ctypes.data_as(C.POINTER(C.c_int64)), 4, 0))
+    _lib.check(lib.svln_kv_reset(h, 0))
+    last = regen(1)
+    h_pre = m.last_hidden()[0]
+    rel = np.linalg.norm(h_pre - h_dec[4]) / np.linalg.norm(h_dec[4])
+    if dtype == torch.float32:
+        assert last == toks[4:5] and rel < 1e-4, (last, toks, rel)
+    else:
+        assert rel < 3e-2, rel
+    m.close()
+
+
+def test_full_size_determinism_and_graph_equivalence():
+    """BASELINE full size (SigLIP-so400m + Qwen2-7B, bf16): two runs of the same turns agree bit for bit, with and without
+    hipGraph replay of the decode step; KV pages recycled by reset_for_env give the same result as fresh ones."""
+    from streamvln_amd.config import TRUE
+    sc = dict(SCENARIOS["true1_episode"], cfg=TRUE)
+    m = StreamVLNForCausalLM(TRUE, dtype=torch.bfloat16, max_envs=1, max_frames=9, max_positions=4096)
+    m.load_synthetic(SEED)
+    m.model.num_history = 8
+    runs = []
+    for graph in (True, False, True):
+        m.set_decode_graph(graph)
+        m.reset_for_env(0)
+        ids, img = _first_turn_inputs(m, sc, n_text=180)
+        o1 = m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=5, eos_token_ids=[])
+        h1 = m.last_hidden()
+        ids2 = torch.cat([o1.sequences.cpu(), torch.tensor([[11, 12, 13, -200, 14]])], 1)
+        o2 = m.generate(inputs=ids2, images=img, env_id=0, time_ids=[[0, 1, 2, 3, 4]], max_new_tokens=5, eos_token_ids=[],
+                        past_key_values=o1.past_key_values)
+        runs.append((o1.sequences[0].tolist(), o2.sequences[0].tolist(), h1, m.last_hidden()))
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1]
+        assert np.array_equal(r[2], runs[0][2]) and np.array_equal(r[3], runs[0][3])
+    assert np.isfinite(runs[0][3]).all()
+    m.close()
