@@ -271,3 +271,57 @@ def test_full_size_determinism_and_graph_equivalence():
         assert np.array_equal(r[2], runs[0][2]) and np.array_equal(r[3], runs[0][3])
     assert np.isfinite(runs[0][3]).all()
     m.close()
+
+
+def test_long_horizon_single_window_vs_live_oracle():
+    """BASELINE configs[3] shape (64-step dialogue in ONE window = 16 turns, KV growing to ~3.4k positions) on the TINY model,
+    fp32 engine against the CPU oracle run live on the same inputs: ids identical, hidden <= 1e-3 at every turn."""
+    from oracle import streamvln_oracle as O
+    from streamvln_amd import weights as W
+    from scenarios import run_scenario
+    sc = dict(SCENARIOS["tiny_episode"], steps=64, num_frames=64, num_history=8, max_new=5, eos_mod=0, lens=(40, 48, 16))
+    cfg = sc["cfg"]
+    m = StreamVLNForCausalLM(cfg, dtype=torch.float32, max_envs=1, max_frames=9, max_positions=4096)
+    m.load_synthetic(SEED)
+    m.model.num_history = 8
+    hid = []
+    pre = m.get_vision_tower().image_processor.preprocess_array
+    log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
+    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=8)
+    log_o = run_scenario(orc, sc, preprocess=pre)
+    assert len(log_g) == len(log_o) == 16
+    for t, (a, b) in enumerate(zip(log_g, log_o)):
+        assert a["out"].sequences[0].tolist() == b["out"].sequences[0].tolist(), t
+        assert np.abs(hid[t] - b["out"].hidden.numpy()).max() <= HIDDEN_TOL, t
+        assert a["out"].past_key_values.get_seq_length() == b["out"].cache_len
+    # first turn 39 text + 196 image rows; every later turn 5 previous tokens + 15 text + 196 image rows; last EOS is not fed
+    assert log_g[-1]["out"].past_key_values.get_seq_length() == 39 + 196 + 15 * (5 + 15 + 196) + 5 - 1
+    m.close()
+
+
+def test_eight_envs_round_robin_equal_their_solo_runs():
+    """BASELINE configs[4] shape (8 concurrent envs on one GPU): turns of 8 envs interleaved round-robin; every env reproduces
+    the token ids it produces when it runs alone (per-env semantics = the batch-1 path)."""
+    sc = SCENARIOS["tiny_episode"]
+    m = StreamVLNForCausalLM(sc["cfg"], dtype=torch.bfloat16, max_envs=8, max_frames=3, max_positions=1024)
+    m.load_synthetic(SEED)
+    m.model.num_history = 2
+    tail = torch.tensor([[7, 8, -200, 9]])
+    inputs = [_first_turn_inputs(m, sc, step=e, seed=10 + e) for e in range(8)]
+    solo = []
+    for e in range(8):
+        m.reset_for_env(0)
+        ids, img = inputs[e]
+        o1 = m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=3, eos_token_ids=[])
+        o2 = m.generate(inputs=torch.cat([o1.sequences.cpu(), tail], 1), images=img, env_id=0, time_ids=[[0, 1, 2, 3, 4]],
+                        max_new_tokens=3, eos_token_ids=[], past_key_values=o1.past_key_values)
+        solo.append(o1.sequences[0].tolist() + o2.sequences[0].tolist())
+    m.reset(8)
+    first = [m.generate(inputs=inputs[e][0], images=inputs[e][1], env_id=e, time_ids=[[0]], max_new_tokens=3, eos_token_ids=[])
+             for e in range(8)]
+    second = [m.generate(inputs=torch.cat([first[e].sequences.cpu(), tail], 1), images=inputs[e][1], env_id=e,
+                         time_ids=[[0, 1, 2, 3, 4]], max_new_tokens=3, eos_token_ids=[], past_key_values=first[e].past_key_values)
+              for e in range(8)]
+    for e in range(8):
+        assert first[e].sequences[0].tolist() + second[e].sequences[0].tolist() == solo[e], e
+    m.close()
