@@ -73,8 +73,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
 
     // Q fragments (B operand of S^T): lane (r,h) holds chunk 2s+h of query row rho
     uint4 qf[G::HDC / 2];
-    const bool fused = WAVES == 1 && HD == 128 && p.fuse_rope_append;
-    const int fpos = fused ? *p.dyn_pos : 0;
     {
         const T* qrow = (const T*)p.Q + (size_t)(frame * p.T + qi) * p.q_stride + (size_t)(head0 + qg) * HD;
 #pragma unroll
@@ -83,28 +81,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
             qf[s] = (valid && e0 < HD) ? *(const uint4*)(qrow + e0) : zero_chunk();
         }
     }
-    if (WAVES == 1 && HD == 128) {
-        if (fused) {
-            // RoPE on q in registers: chunk c = 2s+h (d < 64) pairs with chunk c + HDC/2 = fragment s + HDC/4
-            const float* tab = p.rope_tab + (size_t)fpos * 128;
-#pragma unroll
-            for (int s = 0; s < G::HDC / 4; ++s) {
-                const int d0 = (2 * s + h) * EPC;
-                float x1[EPC], x2[EPC], o1[EPC], o2[EPC];
-                chunk_to_f32<T>(qf[s], x1);
-                chunk_to_f32<T>(qf[s + G::HDC / 4], x2);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float c = tab[d0 + e], sn = tab[64 + d0 + e];
-                    o1[e] = x1[e] * c - x2[e] * sn;
-                    o2[e] = x2[e] * c + x1[e] * sn;
-                }
-                qf[s] = f32_to_chunk<T>(o1);
-                qf[s + G::HDC / 4] = f32_to_chunk<T>(o2);
-            }
-        }
-    }
-
     // key-tile range of this workgroup
     int tiles = (kv_len + 63) >> 6;
     if (p.causal) {
@@ -220,34 +196,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
                             *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(t[u].z, t[u].w);
                         }
                     }
-                }
-            }
-        }
-        if (WAVES == 1 && HD == 128) {
-            if (fused && kt == (fpos >> 6)) {
-                // this workgroup owns the page of the token being decoded: rope its k, append k / v to the pools and
-                // patch the LDS tiles (the staged copy of that slot is stale).  64 threads: d pairs (d, d + 64).
-                __syncthreads();
-                const int off = fpos & 63, d = tid;
-                const T* krow = (const T*)p.Q + (size_t)(p.nq_heads + kh) * 128;
-                const T* vrow = (const T*)p.Q + (size_t)(p.nq_heads + p.n_kv_total + kh) * 128;
-                const float* tab = p.rope_tab + (size_t)fpos * 128;
-                const float k1 = to_f32(krow[d]), k2 = to_f32(krow[d + 64]);
-                const float c = tab[d], sn = tab[64 + d];
-                const T ko1 = from_f32<T>(k1 * c - k2 * sn), ko2 = from_f32<T>(k2 * c + k1 * sn);
-                const T v1 = vrow[d], v2 = vrow[d + 64];
-                T* gk = (T*)(const_cast<char*>(gK)) + (size_t)off * 128;
-                T* gv = (T*)(const_cast<char*>(gV));
-                gk[d] = ko1; gk[d + 64] = ko2;
-                gv[(size_t)d * 64 + off] = v1; gv[(size_t)(d + 64) * 64 + off] = v2;
-                *(T*)(sK + k_off<G>(off, d / EPC) + (d % EPC) * sizeof(T)) = ko1;
-                *(T*)(sK + k_off<G>(off, (d + 64) / EPC) + ((d + 64) % EPC) * sizeof(T)) = ko2;
-                if (sizeof(T) == 4) {
-                    *(T*)(sV + v_off_f32(d, off >> 2) + (off & 3) * 4) = v1;
-                    *(T*)(sV + v_off_f32(d + 64, off >> 2) + (off & 3) * 4) = v2;
-                } else {
-                    *(T*)(sV + v_off_bf16(d, off >> 2) + (off & 3) * 2) = v1;
-                    *(T*)(sV + v_off_bf16(d + 64, off >> 2) + (off & 3) * 2) = v2;
                 }
             }
         }

@@ -372,7 +372,7 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.zeros = zero_line; a.w_tiled = 0; a.force_cfg = 0; a.force_split = 0; return a;
+        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -867,7 +867,7 @@ int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw,
                  int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split) {
     API_BEGIN
     GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
-    a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = nullptr; a.ws_elems = 0; a.nsplit = 1; a.zeros = nullptr; a.w_tiled = 0; a.force_cfg = force_cfg; a.force_split = force_split;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = nullptr; a.ws_elems = 0; a.nsplit = 1; a.zeros = nullptr; a.force_cfg = force_cfg; a.force_split = force_split;
     h->impl->op_gemm(a);
     API_END
 }

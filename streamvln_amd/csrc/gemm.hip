@@ -79,7 +79,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
 
     const T* A = (const T*)p.A;
     const T* W = (const T*)p.W;
-    const bool w_nt = tiles_m == 1 && !(p.force_cfg & 0x1000);
+    const bool w_nt = tiles_m == 1;
 
     struct Regs { uint4 a[C::A_LOADS]; uint4 w[C::W_LOADS]; };
     auto load_stage = [&](Regs& rg, int st) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 
     // per-lane source pointers (at K stage 0) and wave-uniform LDS offsets of this wave's 1-KiB blocks
     const char* src[PER_WAVE];
-    int cj[PER_WAVE], loff[PER_WAVE], wstep[PER_WAVE];
+    int cj[PER_WAVE], loff[PER_WAVE];
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
         const int b = wave + WAVES * j;
@@ -294,16 +294,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         cj[j] = c;
         loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
         if (isA) src[j] = (const char*)((const T*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
-        else if (p.w_tiled) src[j] = (const char*)p.W + ((size_t)bn * stages_total * C::BN + row) * C::ROWB + c * 16;
         else src[j] = (const char*)((const T*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
-        wstep[j] = (!isA && p.w_tiled) ? C::BN * C::ROWB : C::ROWB;
     }
     auto issue = [&](int st, int buf) {
         char* base = smem + buf * C::STAGE_BYTES;
         const bool full = (st + 1) * C::CH <= kchunks;
 #pragma unroll
         for (int j = 0; j < PER_WAVE; ++j) {
-            const char* g = src[j] + (size_t)((p.force_cfg & 0x8000) ? 0 : st) * wstep[j];    // 0x8000: timing experiment (no K advance)
+            const char* g = src[j] + (size_t)st * C::ROWB;
             if (!full && st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
         }
@@ -504,7 +502,6 @@ template <typename T, int EPI> void launch_split(hipStream_t s, GemmArgs a, int 
 
 template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return;
-    if (a.force_cfg & 0x4000) a.w_tiled = 1;        // timing experiments only
     constexpr int EPC = Elt<T>::PER_CHUNK;
     a.tile_base = 0;
     // Tile choice (measured on MI355X, tools/kbench.py):

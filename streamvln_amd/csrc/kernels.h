@@ -23,7 +23,6 @@ struct GemmArgs {
     float* ws; size_t ws_elems;   // split-K slab workspace (fp32) or null
     int nsplit, tile_base, launch_tiles;   // filled by the launcher (K splits; first column tile and tile count of this launch)
     const void* zeros;            // >= 16 B of zeros in device memory (K-tail source of the LDS-DMA path); null -> register-staged kernel
-    int w_tiled;                  // W is stored as [N/128][K stages][128 rows][128 B] (weight panel of a stage contiguous)
     int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a);

@@ -325,3 +325,26 @@ def test_eight_envs_round_robin_equal_their_solo_runs():
     for e in range(8):
         assert first[e].sequences[0].tolist() + second[e].sequences[0].tolist() == solo[e], e
     m.close()
+
+
+def test_from_pretrained_safetensors_equals_synthetic(tmp_path):
+    """checkpoint ingestion (HF state-dict names, bf16 safetensors shards) gives the same engine as on-device synthesis"""
+    from safetensors.torch import save_file
+    from streamvln_amd import weights as W
+    sc = SCENARIOS["tiny_episode"]
+    cfg = sc["cfg"]
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in W.synth_state_dict(cfg, SEED).items()}
+    names = sorted(sd)
+    save_file({k: sd[k] for k in names[: len(names) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in names[len(names) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    a = StreamVLNForCausalLM.from_pretrained(str(tmp_path), config=cfg, torch_dtype=torch.bfloat16, max_frames=3, max_positions=1024)
+    b = _model(sc, torch.bfloat16)
+    for n in ("model.layers.1.mlp.up_proj.weight", "model.layers.0.self_attn.k_proj.bias", "lm_head.weight"):
+        assert np.array_equal(a.get_tensor(n), b.get_tensor(n)), n
+    ids, img = _first_turn_inputs(a, sc)
+    oa = a.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=4, eos_token_ids=[])
+    ob = b.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=4, eos_token_ids=[])
+    assert oa.sequences.tolist() == ob.sequences.tolist() and np.array_equal(a.last_hidden(), b.last_hidden())
+    with pytest.raises(Exception):
+        StreamVLNForCausalLM.from_pretrained(str(tmp_path / "missing"), config=cfg)
+    a.close(); b.close()

@@ -130,3 +130,50 @@ def test_engine_fails_loudly_without_a_gpu():
     from streamvln_amd.model import StreamVLNForCausalLM
     with pytest.raises(_lib.SvlnError):
         StreamVLNForCausalLM(TINY)
+
+
+class StubTokenizer:
+    """whitespace tokenizer with the methods preprocess_qwen uses"""
+
+    def __init__(self):
+        self.vocab, self.chat_template = {}, None
+
+    def _id(self, w):
+        return self.vocab.setdefault(w, 100 + len(self.vocab))
+
+    def add_tokens(self, toks, special_tokens=False):
+        for t in toks:
+            self._id(t)
+
+    def convert_tokens_to_ids(self, t):
+        return self._id(t)
+
+    def apply_chat_template(self, msgs):
+        out = []
+        for m in msgs:
+            text = "<|im_start|> " + m["role"] + " \n " + m["content"].replace("<image>", " <image> ").replace("<memory>", " <memory> ") + " <|im_end|> \n"
+            out += [self._id(w) for w in text.split(" ") if w]
+        return out
+
+
+def test_qwen_prompt_encoder_follows_preprocess_qwen():
+    from streamvln_amd.prompt import QwenPromptEncoder
+    tok = StubTokenizer()
+    enc = QwenPromptEncoder(tok, flavour="agent")
+    inv = lambda ids: [k for t in ids for k, v in enc.tok.vocab.items() if v == t]
+    first = enc(True, False, "walk to the kitchen")
+    assert first.count(IMAGE_TOKEN_INDEX) == 1 and first.count(MEMORY_TOKEN_INDEX) == 0
+    words = inv([t for t in first if t >= 0])
+    assert words[:3] == ["<|im_start|>", "system", "\n"] and "kitchen" in words and "<video>" not in words
+    assert first[-8:].count(IMAGE_TOKEN_INDEX) == 0 and words[-5:] == ["<|im_start|>", "assistant", "\n", "<|im_end|>", "\n"]
+    mem = enc(True, True, "walk")
+    assert mem.count(MEMORY_TOKEN_INDEX) == 1 and mem.index(MEMORY_TOKEN_INDEX) < mem.index(IMAGE_TOKEN_INDEX)
+    assert "visited" in inv([t for t in mem if t >= 0])
+    later = enc(False, False)
+    assert later.count(IMAGE_TOKEN_INDEX) == 1 and inv([t for t in later if t >= 0])[:2] == ["<|im_start|>", "user"]   # no system turn
+    ev = QwenPromptEncoder(tok, flavour="eval")
+    ev_words = [k for t in ev(True, True, "x") if t >= 0 for k, v in ev.tok.vocab.items() if v == t]
+    assert "historical" in ev_words and "visited" not in ev_words
+    ag = StreamingAgent(FakeModel(), enc, num_frames=8, preprocess=lambda rgb: torch.zeros(3, 4, 4))
+    ag.act(0, "go left")
+    assert ag.model.calls[0]["inputs"].shape[1] == len(enc(True, False, "go left"))
