@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-feature-cache-pass", action="store_true")
+    ap.add_argument("--no-batched-pass", action="store_true")
+    ap.add_argument("--batched-envs", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
@@ -148,7 +150,8 @@ def main():
     torch.cuda.set_device(local)
     cfg = CONFIGS[a.config]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = StreamVLNForCausalLM(cfg, dtype=dtype, device=local, max_envs=1, max_frames=1 + NUM_HISTORY)
+    n_benv = 1 if a.no_batched_pass else a.batched_envs
+    model = StreamVLNForCausalLM(cfg, dtype=dtype, device=local, max_envs=n_benv, max_frames=1 + NUM_HISTORY)
     model.load_synthetic(a.seed)
     model.model.num_history = NUM_HISTORY
     model.set_decode_graph(not a.no_graph)
@@ -224,6 +227,51 @@ def main():
                   "hits": hits, "misses": misses,
                   "note": "opt-in: pooled features of frames already encoded in the episode are reused (content hash) instead of "
                           "re-running the ViT on the 8 <memory> frames; not the headline value"}
+    # third pass: BASELINE configs[4]-style concurrent envs on this GPU, stepped in lockstep through generate_batch
+    # (build-side extension; the headline `value` is the 1-env-per-GPU stream of configs[1]).
+    batched = None
+    if not a.no_batched_pass and n_benv > 1:
+        from streamvln_amd.agent import BatchedAgents, StreamingAgent
+        from streamvln_amd.synthetic import SyntheticPromptEncoder
+        model.set_feature_cache(0)
+        model.reset(n_benv)
+        agents = [StreamingAgent(model, SyntheticPromptEncoder(cfg, seed=7 + 31 * e), num_frames=NUM_FRAMES, num_future_steps=NUM_FUTURE,
+                                 num_history=NUM_HISTORY, env_id=e, device="cuda", max_new_tokens=DECODE_TOKENS, eos_token_ids=(),
+                                 preprocess=lambda idx: run.frames[idx]) for e in range(n_benv)]
+        group = BatchedAgents(agents)
+        bstep = [0]
+
+        def lockstep_turn():
+            n0 = len(agents[0].turn_log)
+            while len(agents[0].turn_log) == n0:
+                if bstep[0] == EP_STEPS:
+                    for ag in agents:
+                        ag.reset_memory()
+                    bstep[0] = 0
+                group.act([(bstep[0] + 7 * e) % EP_STEPS for e in range(n_benv)])       # env e sees the stream shifted by 7e frames
+                bstep[0] += 1
+            for ag in agents:
+                ag.turn_log[:] = ag.turn_log[-1:]
+        for _ in range(a.warmup):
+            lockstep_turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0b = time.perf_counter()
+        for _ in range(a.steps):
+            lockstep_turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtb = time.perf_counter() - t0b
+        if world > 1:
+            tt = torch.tensor([dtb], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+        batched = {"envs_per_gpu": n_benv, "value": round(NUM_FUTURE * n_benv * a.steps * world / dtb, 2), "unit": "action-steps/s",
+                   "per_gpu": round(NUM_FUTURE * n_benv * a.steps / dtb, 2), "ms_per_lockstep_turn": round(dtb / a.steps * 1e3, 3),
+                   "note": "BASELINE configs[4]-style: envs_per_gpu concurrent envs stepped in lockstep (batched prefill rows + batched "
+                           "decode steps, bf16); not the headline value"}
     # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
     summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     turns_total = a.steps * world
@@ -244,6 +292,7 @@ def main():
             "metric_allreduce_check": summary,
             "roofline": roof,
             "with_feature_cache": cached,
+            "batched_envs": batched,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(CONFIGS["streamvln_qwen2_7b"])

@@ -71,6 +71,16 @@ int svln_generate(svln_engine* h, int env, int max_new_tokens, const int64_t* eo
 /* perf harness variant: decode exactly n_tokens regardless of EOS */
 int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out_ids);
 
+/* -- multi-env lockstep turns (SURVEY.md 8f-1 / BASELINE configs[4]; build-side extension, the reference runs batch 1):
+ * svln_append_turn_at = svln_append_turn with the env's frames starting at `frame_base` of the last svln_encode_frames
+ * call (several envs' frames encoded together); svln_generate_batch = svln_generate on each listed env (<= 8, distinct),
+ * executed together: dense layers of all prefill rows at once, then batched decode steps that stream each weight matrix
+ * once per step for all still-active envs.  out_ids is [n_envs][out_cap], n_out is [n_envs]. */
+int svln_append_turn_at(svln_engine* h, int env, const int64_t* ids, int n_ids, int frame_base, int n_memory);
+int svln_generate_batch(svln_engine* h, const int32_t* envs, int n_envs, int max_new_tokens, const int64_t* eos_ids, int n_eos,
+                        int64_t* out_ids, int out_cap, int32_t* n_out);
+int svln_get_hidden_batch(svln_engine* h, int slot, float* host_out, int max_rows, int32_t* n_rows);   /* parity tap, <= 8 rows */
+
 /* -- parity taps (test infrastructure reads these; not used by the product path) */
 int svln_get_hidden(svln_engine* h, float* host_out, int max_rows, int32_t* n_rows);  /* final-norm hidden per generated token of the last generate */
 int svln_get_embeds(svln_engine* h, int env, int start_row, int n_rows, float* host_out);

@@ -43,6 +43,9 @@ SIGNATURES = {
     "svln_env_state": (_I, [_P, _I, _PI32, _PI32]),
     "svln_encode_frames": (_I, [_P, _P, _I, _I]),
     "svln_append_turn": (_I, [_P, _I, _PI64, _I, _I]),
+    "svln_append_turn_at": (_I, [_P, _I, _PI64, _I, _I, _I]),
+    "svln_generate_batch": (_I, [_P, _PI32, _I, _I, _PI64, _I, _PI64, _I, _PI32]),
+    "svln_get_hidden_batch": (_I, [_P, _I, _PF, _I, _PI32]),
     "svln_generate": (_I, [_P, _I, _I, _PI64, _I, _PI64, _I, _PI32]),
     "svln_generate_fixed": (_I, [_P, _I, _I, _PI64]),
     "svln_get_hidden": (_I, [_P, _PF, _I, _PI32]),

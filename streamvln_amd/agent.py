@@ -76,7 +76,7 @@ class StreamingAgent:
         self.model.reset_for_env(self.env_id)
 
     # -- one model turn ---------------------------------------------------------------
-    def _turn(self, instruction: str):
+    def _build_request(self, instruction: str) -> dict:
         first = self.output_ids is None
         with_memory = first and self.step_id != 0
         ids = torch.tensor([self.prompt_encoder(first, with_memory, instruction)], dtype=torch.long)
@@ -91,29 +91,33 @@ class StreamingAgent:
                 hist = slice(0, t0, t0 // self.num_history)
             images = self.rgb_list[hist] + images
         V = len(images)
-        batch = {
+        self._pending = {"step_id": self.step_id, "n_inputs": int(ids.shape[1]), "views": V, "memory": bool(with_memory)}
+        return {
             "images": torch.stack(images).unsqueeze(0).to(self.device).to(self.image_dtype),
             # depths / poses / intrinsics are built by the reference callers and ignored by the model
             "depths": torch.zeros(1, V, 1, 1), "poses": torch.zeros(1, V, 4, 4), "intrinsics": torch.zeros(1, V, 4, 4),
             "inputs": ids.to(self.device), "env_id": self.env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
+            "do_sample": False, "num_beams": 1, "max_new_tokens": self.max_new_tokens, "use_cache": True,
+            "return_dict_in_generate": True, "past_key_values": self.past_key_values, "eos_token_ids": self.eos_token_ids,
         }
-        out = self.model.generate(**batch, do_sample=False, num_beams=1, max_new_tokens=self.max_new_tokens,
-                                  use_cache=True, return_dict_in_generate=True,
-                                  past_key_values=self.past_key_values, eos_token_ids=self.eos_token_ids)
+
+    def _consume(self, out):
         self.output_ids = out.sequences
         self.past_key_values = out.past_key_values
-        self.turn_log.append({"step_id": self.step_id, "n_inputs": int(ids.shape[1]), "views": V,
-                              "memory": bool(with_memory), "out": out})
+        self.turn_log.append(dict(self._pending, out=out))
         actions = list(self.decode_actions(out.sequences))
         return actions if len(actions) else [0]               # streamvln_eval.py:340-341
 
-    # -- eval-loop flavour: one env step, returns the action taken -------------------
-    def act(self, rgb: np.ndarray, instruction: str = "") -> int:
-        """One environment step of the Habitat loop (streamvln_eval.py:247-350)."""
+    def _turn(self, instruction: str):
+        return self._consume(self.model.generate(**self._build_request(instruction)))
+
+    # -- split form of act() used by BatchedAgents: observe -> (maybe) request -> finish ----------
+    def observe(self, rgb):
         self.time_ids.append(self.step_id)
         self.rgb_list.append(self.preprocess(rgb))
-        if len(self.action_seq) == 0:
-            self.action_seq = self._turn(instruction)
+        return len(self.action_seq) == 0                      # True: this env needs a model turn now
+
+    def finish_step(self) -> int:
         action = self.action_seq.pop(0)
         self.step_id += 1
         if self.step_id % self.num_frames == 0:
@@ -122,6 +126,13 @@ class StreamingAgent:
             self.past_key_values = None
             self.time_ids = []
         return action
+
+    # -- eval-loop flavour: one env step, returns the action taken -------------------
+    def act(self, rgb: np.ndarray, instruction: str = "") -> int:
+        """One environment step of the Habitat loop (streamvln_eval.py:247-350)."""
+        if self.observe(rgb):
+            self.action_seq = self._turn(instruction)
+        return self.finish_step()
 
     # -- real-world flavour ------------------------------------------------------------
     def step(self, idx: int, rgb: np.ndarray, instruction_text: str = "", run_model: bool = False):
@@ -141,3 +152,24 @@ class StreamingAgent:
             return None, 0, None
         actions = self._turn(instruction_text)
         return actions, 0.0, self.turn_log[-1]["out"]
+
+
+class BatchedAgents:
+    """Several envs on one GPU stepped in lockstep (BASELINE configs[4]: DAgger-style concurrent envs; the reference
+    runs one env per process, streamvln_dagger.py:299).  Each env keeps its own StreamingAgent state; the turns that fall
+    due at the same step are sent to the model together (`generate_batch`)."""
+
+    def __init__(self, agents):
+        self.agents = list(agents)
+        self.model = self.agents[0].model
+
+    def act(self, rgbs, instructions=None):
+        instructions = instructions or [""] * len(self.agents)
+        due = [a for a, rgb in zip(self.agents, rgbs) if a.observe(rgb)]
+        if due:
+            reqs = [a._build_request(instructions[self.agents.index(a)]) for a in due]
+            shared = {k: reqs[0][k] for k in ("max_new_tokens", "eos_token_ids")}
+            outs = self.model.generate_batch(reqs, **shared)
+            for a, out in zip(due, outs):
+                a.action_seq = a._consume(out)
+        return [a.finish_step() for a in self.agents]

@@ -341,10 +341,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     char* sV = smem + G::K_TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int kh = blockIdx.x, z = blockIdx.y;
+    const int kh = blockIdx.x, z = blockIdx.y, env = blockIdx.z;
     const int kt0 = z * p.tiles_per_split;
-    const int page0 = p.page_table[kt0];
-    const int pos = *p.dyn_pos;
+    const int* page_table = p.slots ? p.slots[env].page_table : p.page_table;
+    const int page0 = page_table[kt0];
+    const int pos = p.slots ? p.slots[env].pos : *p.dyn_pos;
+    const T* qkv_row = (const T*)p.Q + (size_t)env * p.q_stride;
     const int kv_len = pos + 1;
     const int tiles = (kv_len + 63) >> 6;
     if (kt0 >= tiles) return;                                   // combine only reads splits below ceil(tiles / tiles_per_split)
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     // roped Q fragments of row rho = r (q head kh*G + r), identical in every wave
     uint4 qf[G::HDC / 2];
     {
-        const T* qrow = (const T*)p.Q + (size_t)(kh * p.G + (valid ? r : 0)) * 128;
+        const T* qrow = qkv_row + (size_t)(kh * p.G + (valid ? r : 0)) * 128;
 #pragma unroll
         for (int s = 0; s < G::HDC / 2; ++s) qf[s] = valid ? *(const uint4*)(qrow + (2 * s + h) * EPC) : zero_chunk();
         const float* tab = p.rope_tab + (size_t)pos * 128;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     float m = -INFINITY, l = 0.0f;
 
     for (int kt = kt0; kt < kt_end; ++kt) {
-        const int page = kt == kt0 ? page0 : p.page_table[kt];
+        const int page = kt == kt0 ? page0 : page_table[kt];
         const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * 128 * sizeof(T);
         const char* gV = (const char*)p.Vpool + (size_t)page * k_page_stride + (size_t)kh * 128 * 64 * sizeof(T);
         constexpr int KL = 64 * G::HDC / NT, VL = 128 * G::VC / NT;
@@ -411,8 +413,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
             __syncthreads();
             if (tid < 64) {
                 const int off = pos & 63, d = tid;
-                const T* krow = (const T*)p.Q + (size_t)(p.nq_heads + kh) * 128;
-                const T* vrow = (const T*)p.Q + (size_t)(p.nq_heads + p.n_kv_total + kh) * 128;
+                const T* krow = qkv_row + (size_t)(p.nq_heads + kh) * 128;
+                const T* vrow = qkv_row + (size_t)(p.nq_heads + p.n_kv_total + kh) * 128;
                 const float* tab = p.rope_tab + (size_t)pos * 128;
                 const float k1 = to_f32(krow[d]), k2 = to_f32(krow[d + 64]);
                 const float c = tab[d], sn = tab[64 + d];
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     }
     l += __shfl_xor(l, 32, 64);
     if (!valid) return;
-    float* dst = p.part + (((size_t)z * p.n_kv_total + kh) * p.rows_pad + r) * 130;
+    float* dst = p.part + (size_t)env * p.part_bstride + (((size_t)z * p.n_kv_total + kh) * p.rows_pad + r) * 130;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dst[wave * 32 + acc_row(e, lane)] = O[e];
     if (wave == 0 && h == 0) { dst[128] = m; dst[129] = l; }
@@ -509,12 +511,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 template <typename T, int HD>
 __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
     __shared__ float wsh[64];
-    const int rho = blockIdx.x, kh = blockIdx.y, lane = threadIdx.x;
-    const int kv_len = p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len;
+    const int rho = blockIdx.x, kh = blockIdx.y, env = blockIdx.z, lane = threadIdx.x;
+    const int kv_len = p.slots ? p.slots[env].pos + 1 : (p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len);
     const int tiles = (kv_len + 63) >> 6;
     const int nsplit = min(min(p.nsplit, 64), (tiles + p.tiles_per_split - 1) / p.tiles_per_split);
     const size_t split_stride = (size_t)p.n_kv_total * p.rows_pad * (HD + 2);
-    const float* base = p.part + ((size_t)kh * p.rows_pad + rho) * (HD + 2);
+    const float* base = p.part + (size_t)env * p.part_bstride + ((size_t)kh * p.rows_pad + rho) * (HD + 2);
     float mz = -INFINITY, lz = 0.0f;
     if (lane < nsplit) { mz = base[lane * split_stride + HD]; lz = base[lane * split_stride + HD + 1]; }
     const float mstar = wave_max(mz);
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
     const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;
     const int qi = rho / p.G, qg = rho - qi * p.G;
     const int frame = kh / p.hpf, head0 = (kh % p.hpf) * p.G;
-    T* orow = (T*)p.O + (size_t)(frame * p.T + qi) * p.o_stride + (size_t)(head0 + qg) * HD;
+    T* orow = (T*)p.O + (size_t)(frame * p.T + qi + env) * p.o_stride + (size_t)(head0 + qg) * HD;     // env > 0 only when T == 1
     if (lane < HD) orow[lane] = from_f32<T>(o0 * inv);
     if (lane + 64 < HD) orow[lane + 64] = from_f32<T>(o1 * inv);
 }
@@ -550,7 +552,7 @@ template <typename T, int HD, int WAVES> void launch_attn_t(hipStream_t s, const
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves) {
     if (head_dim == 128 && waves == 1 && a.fuse_rope_append && a.T == 1) {
         using G = AttnGeom<T, 128>;
-        hipLaunchKernelGGL((attn_decode_kernel<T>), dim3(a.n_kv_total, a.nsplit), dim3(256), G::K_TILE_BYTES + G::V_TILE_BYTES, s, a);
+        hipLaunchKernelGGL((attn_decode_kernel<T>), dim3(a.n_kv_total, a.nsplit, a.batch > 0 ? a.batch : 1), dim3(256), G::K_TILE_BYTES + G::V_TILE_BYTES, s, a);
         return;
     }
     if (head_dim == 128) {
@@ -560,7 +562,7 @@ template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, in
     }
 }
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim) {
-    dim3 grid(a.T * a.G, a.n_kv_total), block(64);
+    dim3 grid(a.T * a.G, a.n_kv_total, a.batch > 0 ? a.batch : 1), block(64);
     if (head_dim == 128) hipLaunchKernelGGL((attn_combine_kernel<T, 128>), grid, block, 0, s, a);
     else if (head_dim == 72) hipLaunchKernelGGL((attn_combine_kernel<T, 72>), grid, block, 0, s, a);
 }

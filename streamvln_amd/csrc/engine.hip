@@ -54,8 +54,10 @@ struct EngineBase {
     virtual void kv_reset(int env) = 0;
     virtual void env_state(int env, int32_t* n_embeds, int32_t* kv_len) = 0;
     virtual void encode_frames(const float* pixels, int F, int on_device) = 0;
-    virtual void append_turn(int env, const int64_t* ids, int n, int n_memory) = 0;
+    virtual void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) = 0;
     virtual void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) = 0;
+    virtual void generate_batch(const int32_t* envs, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) = 0;
+    virtual void get_hidden_batch(int slot, float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_hidden(float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_embeds(int env, int start, int n, float* out) = 0;
     virtual void get_feats(int start, int n, float* out) = 0;
@@ -109,6 +111,10 @@ public:
     float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
     int* d_dyn;                  // [0] = position of the token being decoded, [1] = kv_len after it
+    // batched (multi-env lockstep) decode
+    static constexpr int MAXB = 8;
+    DecodeSlot* d_slots = nullptr; DecodeSlot* h_slots = nullptr; int* d_tok_b = nullptr; int* h_tok_b = nullptr;
+    float* part_val_b = nullptr; int* part_idx_b = nullptr; T* last_rows = nullptr; int n_generated_b[MAXB] = {0};
     int* d_src; int* h_src;      // splice descriptors
     int* h_token;                // pinned
     float* h_top2;
@@ -262,12 +268,17 @@ public:
         while ((pages_per_env + tiles_per_split - 1) / tiles_per_split > 64) ++tiles_per_split;
         nsplit_max = (pages_per_env + tiles_per_split - 1) / tiles_per_split;
         {   // partials: decode [nsplit_max][nkv][32][130], prefill split-KV [<= 8][nkv][PREFILL_SPLIT_ROWS][130]
-            const size_t dec = (size_t)nsplit_max * nkv * 32 * 130, pre = (size_t)8 * nkv * PREFILL_SPLIT_ROWS * 130;
+            const size_t dec = (size_t)MAXB * nsplit_max * nkv * 32 * 130, pre = (size_t)8 * nkv * PREFILL_SPLIT_ROWS * 130;
             attn_part_elems = dec > pre ? dec : pre;
             attn_part = dalloc<float>(attn_part_elems);
         }
         part_val = dalloc<float>(2048); part_idx = dalloc<int>(2048);
         d_token = dalloc<int>(4, true); d_top2 = dalloc<float>(4, true); d_dyn = dalloc<int>(4, true);
+        d_slots = dalloc<DecodeSlot>(MAXB, true); d_tok_b = dalloc<int>(MAXB, true);
+        part_val_b = dalloc<float>((size_t)MAXB * 2048); part_idx_b = dalloc<int>((size_t)MAXB * 2048);
+        last_rows = dalloc<T>((size_t)MAXB * H);
+        HIP_CHECK(hipHostMalloc((void**)&h_slots, MAXB * sizeof(DecodeSlot)));
+        HIP_CHECK(hipHostMalloc((void**)&h_tok_b, MAXB * sizeof(int)));
         d_src = dalloc<int>(rt);
         HIP_CHECK(hipHostMalloc((void**)&h_src, rt * sizeof(int)));
         HIP_CHECK(hipHostMalloc((void**)&h_token, 16));
@@ -294,6 +305,7 @@ public:
         if (h_hash) (void)hipHostFree(h_hash);
         for (void* p : allocs) (void)hipFree(p);
         (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
+        (void)hipHostFree(h_slots); (void)hipHostFree(h_tok_b);
         (void)hipStreamDestroy(st);
     }
 
@@ -494,10 +506,10 @@ public:
     }
 
     // ------------------------------------------------------------------------------- splice
-    void append_turn(int env, const int64_t* ids, int n, int n_memory) override {
+    void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) override {
         Env& e = env_at(env);
-        REQUIRE(n_memory >= 0 && n_memory <= n_feat_frames, "n_memory exceeds encoded frames");
-        int rows = 0, img = n_memory, mem_used = 0;
+        REQUIRE(frame_base >= 0 && n_memory >= 0 && frame_base + n_memory <= n_feat_frames, "n_memory exceeds encoded frames");
+        int rows = 0, img = frame_base + n_memory, mem_used = 0;
         const int cap = c.max_positions - e.n_embeds;
         for (int k = 0; k < n; ++k) {
             const int64_t t = ids[k];
@@ -509,7 +521,7 @@ public:
             } else if (t == MEMORY_TOKEN) {
                 REQUIRE(n_memory > 0 && mem_used == 0, "<memory> token without (or with repeated) memory frames");
                 REQUIRE(rows + n_memory * otok <= cap, "inputs_embeds exceeds max_positions");
-                for (int j = 0; j < n_memory * otok; ++j) h_src[rows++] = -(1 + j);
+                for (int j = 0; j < n_memory * otok; ++j) h_src[rows++] = -(1 + frame_base * otok + j);
                 mem_used = 1;
             } else {
                 REQUIRE(t >= 0 && t < V, "token id out of range");
@@ -547,26 +559,35 @@ public:
         return a;
     }
 
-    void prefill(Env& e, int P, int Tn) {
-        HIP_CHECK(hipMemcpyAsync(x, e.embeds + (size_t)P * H, (size_t)Tn * H * sizeof(T), hipMemcpyDeviceToDevice, st));
+    struct Seg { Env* e; int P, Tn, off; };       // rows [off, off + Tn) of the prefill batch belong to env e at positions P..
+    // Qwen2DecoderLayer stack (modeling_qwen2.py:269-299) over the concatenated new rows of one or several envs:
+    // the dense products run once on all rows; RoPE + KV append and attention run per env (own pages / positions).
+    void prefill_rows(const std::vector<Seg>& segs, int M) {
         const int qd = nq * 128;
-        for (int i = 0; i < c.layers; ++i) {       // Qwen2DecoderLayer (modeling_qwen2.py:269-299)
+        for (const Seg& g : segs)
+            HIP_CHECK(hipMemcpyAsync(x + (size_t)g.off * H, g.e->embeds + (size_t)g.P * H, (size_t)g.Tn * H * sizeof(T), hipMemcpyDeviceToDevice, st));
+        for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
-            launch_rmsnorm<T>(st, x, L.in_norm, xn, Tn, H, c.rms_eps);
-            launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, Tn, qkv_dim, H, EPI_NONE));
-            RopeKvArgs r; r.qkv = qkv; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = e.d_pages; r.rope_tab = rope_tab;
-            r.T = Tn; r.nq = nq; r.nkv = nkv; r.P = P; r.dyn_pos = nullptr;
-            launch_rope_kv<T>(st, r);
-            {
-                AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, Tn, P, P + Tn, false);
+            launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
+            launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE));
+            for (const Seg& g : segs) {
+                T* q_g = qkv + (size_t)g.off * qkv_dim;
+                RopeKvArgs r; r.qkv = q_g; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = g.e->d_pages; r.rope_tab = rope_tab;
+                r.T = g.Tn; r.nq = nq; r.nkv = nkv; r.P = g.P; r.dyn_pos = nullptr;
+                launch_rope_kv<T>(st, r);
+                AttnArgs a = llm_attn_args(L, *g.e, q_g, qkv_dim, attn + (size_t)g.off * qd, qd, g.Tn, g.P, g.P + g.Tn, false);
                 launch_attention<T>(st, a, 128, 4);
                 if (a.nsplit > 1) launch_attention_combine<T>(st, a, 128);
             }
-            launch_gemm<T>(st, gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, Tn, H, qd, EPI_NONE));
-            launch_rmsnorm<T>(st, x, L.post_norm, xn, Tn, H, c.rms_eps);
-            launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, Tn, 2 * I, H, EPI_SWIGLU));
-            launch_gemm<T>(st, gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, Tn, H, I, EPI_NONE));
+            launch_gemm<T>(st, gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE));
+            launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
+            launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU));
+            launch_gemm<T>(st, gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE));
         }
+    }
+    void prefill(Env& e, int P, int Tn) {
+        std::vector<Seg> segs{Seg{&e, P, Tn, 0}};
+        prefill_rows(segs, Tn);
     }
 
     GemvArgs gemv_args(const void* W, int ldw, const void* xin, const void* norm_w, const void* bias, const void* res, void* y, int N, int K,
@@ -661,6 +682,144 @@ public:
         }
         head(x, tap_row);
         e.kv_len += 1;
+    }
+
+    // ------------------------------------------------------------------------------- multi-env lockstep
+    GemvBatchArgs gemvb_args(const void* W, int ldw, const void* xin, int ldx, const void* norm_w, const void* bias, const void* res, int ldr,
+                             void* y, int ldy, int N, int K, int epi, int B) {
+        GemvBatchArgs a; a.W = W; a.ldw = ldw; a.x = xin; a.ldx = ldx; a.norm_w = norm_w; a.eps = c.rms_eps; a.bias = bias; a.res = res; a.ldr = ldr;
+        a.y = y; a.ldy = ldy; a.N = N; a.K = K; a.epi = epi; a.B = B; a.part_val = part_val_b; a.part_idx = part_idx_b; return a;
+    }
+    // final norm of rows[0..B) -> lm_head once for all B envs -> d_tok_b[0..B)
+    void head_batched(const T* rows, int B) {
+        launch_rmsnorm<T>(st, rows, final_norm, xn, B, H, c.rms_eps);
+        launch_gemv_batched<T>(st, gemvb_args(lm_head, H, xn, H, nullptr, nullptr, nullptr, 0, nullptr, 0, V, H, EPI_ARGMAX, B));
+        launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(V, EPI_ARGMAX), B, d_tok_b);
+    }
+    // One decode step for B envs (B in {1,2,4,8}; d_slots / d_tok_b already set): every weight matrix is streamed once.
+    void decode_ops_batched(int B) {
+        const int qd = nq * 128;
+        launch_gather_rows<T>(st, d_tok_b, embed, feats, x, B, H);
+        for (int i = 0; i < c.layers; ++i) {
+            const LLayer& L = ll[i];
+            launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, x, H, L.in_norm, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
+            AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, qd, 1, 0, 0, true);
+            a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr;
+            a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * 130;
+            launch_attention<T>(st, a, 128, 1);
+            launch_attention_combine<T>(st, a, 128);
+            launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));
+            launch_gemv_batched<T>(st, gemvb_args(L.gu_w, H, x, H, L.post_norm, nullptr, nullptr, 0, hbuf, I, 2 * I, H, EPI_SWIGLU, B));
+            launch_gemv_batched<T>(st, gemvb_args(L.down_w, I, hbuf, I, nullptr, nullptr, x, H, x, H, H, I, EPI_NONE, B));
+        }
+        head_batched(x, B);
+    }
+    bool taps_on = true;
+    void tap_copy(const T* row, int token_idx, int slot) {       // parity tap: hid_tap[min(token,7)][slot]
+        if (!taps_on) return;
+        const int t = token_idx < 8 ? token_idx : 7;
+        HIP_CHECK(hipMemcpyAsync(hid_tap + (size_t)(t * MAXB + slot) * H, row, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+    }
+
+    // Equivalent to svln_generate on each env in turn (per-env semantics = the batch-1 path), executed in lockstep:
+    // prefill rows of all envs through the dense layers together, then decode steps for the still-active envs at once.
+    void generate_batch(const int32_t* env_ids, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap,
+                        int32_t* n_out) override {
+        REQUIRE(n_envs >= 1 && n_envs <= MAXB, "1..8 envs per batch");
+        REQUIRE(weights_missing() == 0, g_err);
+        REQUIRE(max_new >= 1 && cap >= 1, "max_new_tokens must be >= 1");
+        std::vector<Env*> es(n_envs);
+        for (int s = 0; s < n_envs; ++s) {
+            es[s] = &env_at(env_ids[s]);
+            for (int t = 0; t < s; ++t) REQUIRE(env_ids[t] != env_ids[s], "duplicate env in batch");
+            REQUIRE(es[s]->n_embeds - es[s]->kv_len >= 1, "nothing to prefill for an env of the batch");
+        }
+        HIP_CHECK(hipEventRecord(ph_ev[2], st));
+        // ---- prefill in groups whose rows fit the workspaces
+        int s0 = 0;
+        while (s0 < n_envs) {
+            std::vector<Seg> segs;
+            int M = 0, s1 = s0;
+            while (s1 < n_envs) {
+                Env& e = *es[s1];
+                const int Tn = e.n_embeds - e.kv_len;
+                if (!segs.empty() && M + Tn > c.max_positions) break;
+                REQUIRE(Tn <= c.max_positions, "prefill longer than max_positions");
+                ensure_pages(e, e.n_embeds);
+                segs.push_back(Seg{&e, e.kv_len, Tn, M});
+                M += Tn;
+                ++s1;
+            }
+            prefill_rows(segs, M);
+            for (size_t k = 0; k < segs.size(); ++k) {
+                const T* last = x + (size_t)(segs[k].off + segs[k].Tn - 1) * H;
+                HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)(s0 + k) * H, last, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+                segs[k].e->kv_len = segs[k].e->n_embeds;
+            }
+            s0 = s1;
+        }
+        int Bp = 1; while (Bp < n_envs) Bp <<= 1;
+        for (int s = n_envs; s < Bp; ++s)            // pad to a power of two with copies of env slot 0 (results ignored)
+            HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)s * H, last_rows, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+        head_batched(last_rows, Bp);
+        for (int s = 0; s < n_envs; ++s) tap_copy(xn + (size_t)s * H, 0, s);
+        HIP_CHECK(hipEventRecord(ph_ev[3], st));
+
+        std::vector<int> active(n_envs), count(n_envs, 0);
+        for (int s = 0; s < n_envs; ++s) active[s] = s;
+        bool first = true;
+        while (true) {
+            const int Bn = (int)active.size();
+            int Bq = 1; while (Bq < Bn) Bq <<= 1;
+            HIP_CHECK(hipMemcpyAsync(h_tok_b, d_tok_b, Bq * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (first) {
+                float t = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[1] += t;
+                if (vision_pending) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
+                first = false;
+            }
+            std::vector<int> next; std::vector<int> next_tok;
+            for (int k = 0; k < Bn; ++k) {
+                const int s = active[k], tok = h_tok_b[k];
+                if (count[s] < cap) out[(size_t)s * cap + count[s]] = tok;
+                ++count[s];
+                bool stop = count[s] >= max_new || count[s] >= cap;
+                for (int q = 0; q < n_eos; ++q) if (eos[q] == tok) stop = true;
+                if (!stop) { next.push_back(s); next_tok.push_back(tok); }
+            }
+            if (next.empty()) break;
+            active.swap(next);
+            const int Bn2 = (int)active.size();
+            int B = 1; while (B < Bn2) B <<= 1;
+            for (int k = 0; k < B; ++k) {
+                const int kk = k < Bn2 ? k : 0;                         // padding slots replay slot 0 (same writes, ignored outputs)
+                Env& e = *es[active[kk]];
+                REQUIRE(e.kv_len + 1 <= c.max_positions, "sequence exceeds max_positions during decode");
+                if (k < Bn2) ensure_pages(e, e.kv_len + 1);
+                h_slots[k].page_table = e.d_pages; h_slots[k].pos = e.kv_len; h_slots[k].pad = 0;
+                h_tok_b[k] = next_tok[kk];
+            }
+            HIP_CHECK(hipMemcpyAsync(d_slots, h_slots, B * sizeof(DecodeSlot), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(d_tok_b, h_tok_b, B * sizeof(int), hipMemcpyHostToDevice, st));
+            decode_ops_batched(B);
+            for (int k = 0; k < Bn2; ++k) {
+                Env& e = *es[active[k]];
+                e.kv_len += 1;
+                tap_copy(xn + (size_t)k * H, count[active[k]], active[k]);
+            }
+        }
+        HIP_CHECK(hipEventRecord(ph_ev[4], st));
+        HIP_CHECK(hipEventSynchronize(ph_ev[4]));
+        { float t = 0.f; HIP_CHECK(hipEventElapsedTime(&t, ph_ev[3], ph_ev[4])); ph_ms[2] += t; }
+        for (int s = 0; s < n_envs; ++s) { n_out[s] = count[s]; n_generated_b[s] = count[s]; }
+    }
+    void get_hidden_batch(int slot, float* out, int max_rows, int32_t* n_rows) override {
+        REQUIRE(slot >= 0 && slot < MAXB, "slot");
+        int n = n_generated_b[slot] < 8 ? n_generated_b[slot] : 8;
+        if (n > max_rows) n = max_rows;
+        for (int t = 0; t < n; ++t) read_rows_f32(hid_tap + (size_t)(t * MAXB + slot) * H, (size_t)H, out + (size_t)t * H);
+        *n_rows = n;
     }
 
     int read_token() {
@@ -845,7 +1004,15 @@ int svln_reset_env(svln_engine* h, int env) { API_BEGIN h->impl->reset_env(env);
 int svln_kv_reset(svln_engine* h, int env) { API_BEGIN h->impl->kv_reset(env); API_END }
 int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len) { API_BEGIN h->impl->env_state(env, n_embeds, kv_len); API_END }
 int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device) { API_BEGIN h->impl->encode_frames(pixels, n_frames, on_device); API_END }
-int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory) { API_BEGIN h->impl->append_turn(env, ids, n_ids, n_memory); API_END }
+int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory) { API_BEGIN h->impl->append_turn(env, ids, n_ids, 0, n_memory); API_END }
+int svln_append_turn_at(svln_engine* h, int env, const int64_t* ids, int n_ids, int frame_base, int n_memory) {
+    API_BEGIN h->impl->append_turn(env, ids, n_ids, frame_base, n_memory); API_END
+}
+int svln_generate_batch(svln_engine* h, const int32_t* envs, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap,
+                        int32_t* n_out) {
+    API_BEGIN h->impl->generate_batch(envs, n_envs, max_new, eos, n_eos, out, cap, n_out); API_END
+}
+int svln_get_hidden_batch(svln_engine* h, int slot, float* out, int max_rows, int32_t* n_rows) { API_BEGIN h->impl->get_hidden_batch(slot, out, max_rows, n_rows); API_END }
 int svln_generate(svln_engine* h, int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) {
     API_BEGIN h->impl->generate(env, max_new, eos, n_eos, out, cap, n_out, false); API_END
 }

@@ -201,6 +201,147 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_ksplit_kernel(GemvArgs p) {
     }
 }
 
+// Batched decode GEMV for B environments decoded in lockstep (SURVEY.md 8f-1 / BASELINE configs[4]):
+//   Y[b][n] = epi(W[n,:] . x'_b + bias[n]) + res[b][n],   x'_b = x_b or rmsnorm(x_b) * g  (folded, no prologue)
+// Every weight byte is streamed from HBM once for all B activations.  Workgroup = 4 rows (SwiGLU: 2 outputs), its 4 waves
+// split K; per chunk position a lane loads 4 weight chunks (non-temporal) + B activation chunks (L2-resident) and does
+// 4 * B * 8 FMAs.  Partial sums (and the per-env sum of squares) are reduced across waves through LDS.
+template <typename T, int EPI, bool NORM, int B>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_batched_kernel(GemvBatchArgs p) {
+    constexpr int EPC = Elt<T>::PER_CHUNK, R = 4, STRIDE = 64 * GEMV_WAVES;
+    __shared__ float part[GEMV_WAVES][R * B + B];
+    const int nch = p.K / EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const T* W = (const T*)p.W;
+    const T* xg = (const T*)p.x;
+    const T* gg = (const T*)p.norm_w;
+    const int n_units = EPI == EPI_SWIGLU ? p.N / 4 : (p.N + R - 1) / R;      // one unit = R weight rows
+    float best = -INFINITY;                                                   // EPI_ARGMAX: thread b < B tracks env b
+    int best_i = 0x7FFFFFFF;
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const T* rows[R];
+        int n0;
+        if (EPI == EPI_SWIGLU) {          // outputs j0, j0+1: rows gate j0, up j0, gate j0+1, up j0+1 of the [gate 32 | up 32] packing
+            const int j0 = u * 2;
+            n0 = j0;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const size_t gr = (size_t)((j0 + o) >> 5) * 64 + ((j0 + o) & 31);
+                rows[2 * o] = W + gr * p.ldw;
+                rows[2 * o + 1] = W + (gr + 32) * p.ldw;
+            }
+        } else {
+            n0 = u * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, p.N - 1) * p.ldw;
+        }
+        float acc[R][B], ss[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            ss[b] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][b] = 0.0f;
+        }
+        for (int ci = wave * 64 + lane; ci < nch; ci += STRIDE) {
+            uint4 w[R], xr[B];
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[r] = load_nt(rows[r] + (size_t)ci * EPC);
+#pragma unroll
+            for (int b = 0; b < B; ++b) xr[b] = *(const uint4*)(xg + (size_t)b * p.ldx + (size_t)ci * EPC);
+            float gf[EPC];
+            if (NORM) chunk_to_f32<T>(*(const uint4*)(gg + (size_t)ci * EPC), gf);
+            float wf[R][EPC];
+#pragma unroll
+            for (int r = 0; r < R; ++r) chunk_to_f32<T>(w[r], wf[r]);
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                float xf[EPC];
+                chunk_to_f32<T>(xr[b], xf);
+                if (NORM) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { ss[b] = fmaf(xf[e], xf[e], ss[b]); xf[e] *= gf[e]; }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[r][b] = fmaf(wf[r][e], xf[e], acc[r][b]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            if (NORM) ss[b] = wave_sum(ss[b]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][b] = wave_sum(acc[r][b]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                part[wave][R * B + b] = ss[b];
+#pragma unroll
+                for (int r = 0; r < R; ++r) part[wave][r * B + b] = acc[r][b];
+            }
+        }
+        __syncthreads();
+        auto total = [&](int k) { return part[0][k] + part[1][k] + part[2][k] + part[3][k]; };
+        if (EPI == EPI_SWIGLU) {
+            if (tid < 2 * B) {
+                const int o = tid / B, b = tid % B;
+                const float sc = NORM ? rsqrtf(total(R * B + b) / (float)p.K + p.eps) : 1.0f;
+                const float gt = total((2 * o) * B + b) * sc, up = total((2 * o + 1) * B + b) * sc;
+                ((T*)p.y)[(size_t)b * p.ldy + n0 + o] = from_f32<T>(silu_f(gt) * up);
+            }
+        } else if (EPI == EPI_ARGMAX) {
+            if (tid < B) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float v = total(r * B + tid);
+                    if (n0 + r < p.N && v > best) { best = v; best_i = n0 + r; }      // units ascend per workgroup: first max wins
+                }
+            }
+        } else if (tid < R * B) {
+            const int r = tid / B, b = tid % B, n = n0 + r;
+            if (n < p.N) {
+                float v = total(r * B + b);
+                if (NORM) v *= rsqrtf(total(R * B + b) / (float)p.K + p.eps);
+                if (p.bias) v += to_f32(((const T*)p.bias)[n]);
+                if (p.res) v += to_f32(((const T*)p.res)[(size_t)b * p.ldr + n]);
+                ((T*)p.y)[(size_t)b * p.ldy + n] = from_f32<T>(v);
+            }
+        }
+        __syncthreads();
+    }
+    if (EPI == EPI_ARGMAX && tid < B) {
+        p.part_val[(size_t)tid * gridDim.x + blockIdx.x] = best;
+        p.part_idx[(size_t)tid * gridDim.x + blockIdx.x] = best_i;
+    }
+}
+
+// final arg-max of env b = blockIdx.x over its per-workgroup partials
+__global__ __launch_bounds__(256) void argmax_final_batched_kernel(const float* pv, const int* pi, int n, int* out_tokens) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* v0 = pv + (size_t)blockIdx.x * n;
+    const int* i0 = pi + (size_t)blockIdx.x * n;
+    float v = -INFINITY;
+    int i = 0x7FFFFFFF;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float c = v0[k];
+        const int ci = i0[k];
+        if (c > v || (c == v && ci < i)) { v = c; i = ci; }
+    }
+    sv[threadIdx.x] = v; si[threadIdx.x] = i;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            const float b = sv[threadIdx.x + s2];
+            const int bi = si[threadIdx.x + s2];
+            if (b > sv[threadIdx.x] || (b == sv[threadIdx.x] && bi < si[threadIdx.x])) { sv[threadIdx.x] = b; si[threadIdx.x] = bi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_tokens[blockIdx.x] = si[0];
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -349,6 +490,34 @@ template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, h
     }
 }
 #undef SVLN_LAUNCH
+int gemv_batched_grid(int N, int epi) {
+    const int units = epi == EPI_SWIGLU ? N / 4 : (N + 3) / 4;
+    return units < 2048 ? (units < 1 ? 1 : units) : 2048;
+}
+template <typename T, int EPI, bool NORM> static void launch_gb(hipStream_t s, const GemvBatchArgs& a) {
+    dim3 g(gemv_batched_grid(a.N, EPI)), b(GEMV_THREADS);
+    switch (a.B) {
+        case 1: hipLaunchKernelGGL((gemv_batched_kernel<T, EPI, NORM, 1>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((gemv_batched_kernel<T, EPI, NORM, 2>), g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((gemv_batched_kernel<T, EPI, NORM, 4>), g, b, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((gemv_batched_kernel<T, EPI, NORM, 8>), g, b, 0, s, a); break;
+        default: break;
+    }
+}
+template <typename T> void launch_gemv_batched(hipStream_t s, const GemvBatchArgs& a) {
+    const bool norm = a.norm_w != nullptr;
+    switch (a.epi) {
+        case EPI_NONE: if (norm) launch_gb<T, EPI_NONE, true>(s, a); else launch_gb<T, EPI_NONE, false>(s, a); break;
+        case EPI_SWIGLU: if (norm) launch_gb<T, EPI_SWIGLU, true>(s, a); else launch_gb<T, EPI_SWIGLU, false>(s, a); break;
+        case EPI_ARGMAX: if (norm) launch_gb<T, EPI_ARGMAX, true>(s, a); else launch_gb<T, EPI_ARGMAX, false>(s, a); break;
+        default: break;
+    }
+}
+template void launch_gemv_batched<bf16>(hipStream_t, const GemvBatchArgs&);
+template void launch_gemv_batched<float>(hipStream_t, const GemvBatchArgs&);
+void launch_argmax_final_batched(hipStream_t s, const float* pv, const int* pi, int n, int B, int* out_tokens) {
+    hipLaunchKernelGGL(argmax_final_batched_kernel, dim3(B), dim3(256), 0, s, pv, pi, n, out_tokens);
+}
 template void launch_gemv_timed<bf16>(hipStream_t, const GemvArgs&, hipEvent_t, hipEvent_t);
 template void launch_gemv_timed<float>(hipStream_t, const GemvArgs&, hipEvent_t, hipEvent_t);
 template <typename T, int EPI> static void gemv_attr() {

@@ -44,6 +44,22 @@ struct GemvArgs {
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, hipEvent_t start, hipEvent_t stop);   // events get the kernel's own begin/end
 int gemv_grid(int N);                       // workgroups launch_gemv uses for N rows
+
+// B (1, 2, 4 or 8) activation vectors against one weight stream: x [B][ldx], y [B][ldy], res [B][ldr].
+// EPI_ARGMAX: part_val / part_idx are [B][gemv_batched_grid(N, epi)]; launch_argmax_final_batched reduces them to B tokens.
+struct GemvBatchArgs {
+    const void* W; int ldw;
+    const void* x; int ldx;
+    const void* norm_w; float eps;
+    const void* bias;
+    const void* res; int ldr;
+    void* y; int ldy;
+    int N, K, epi, B;
+    float* part_val; int* part_idx;
+};
+template <typename T> void launch_gemv_batched(hipStream_t s, const GemvBatchArgs& a);
+int gemv_batched_grid(int N, int epi);
+void launch_argmax_final_batched(hipStream_t s, const float* part_val, const int* part_idx, int n, int B, int* out_tokens);
 void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token,
                          float* out_top /*[2]: best, runner-up of partial maxima (diagnostic)*/);
 
@@ -52,6 +68,9 @@ void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_i
 //           Vt [page][n_kv_total][DT*32][64]      DT = ceil(HD/32); transposed so keys are contiguous
 //   rows of one "kv head" kh: rho = i*G + g  (query position i, q-head g of the group)
 //   Q/O element (frame, i, head, d) at  ((frame*T + i) * stride) + head*HD + d, head = (kh % hpf)*G + g
+// one environment of a batched decode step
+struct DecodeSlot { const int* page_table; int pos; int pad; };
+
 struct AttnArgs {
     const void* Q; int q_stride;
     void* O; int o_stride;
@@ -73,6 +92,11 @@ struct AttnArgs {
     const float* rope_tab;        // [max_positions][128]: cos[64] | sin[64]
     const int* dyn_pos;
     int nq_heads;
+    // batched decode (gridDim.z = environments): per-env page table / position; Q, O and the partials advance by
+    // q_stride, o_stride and part_bstride per environment
+    const DecodeSlot* slots;
+    size_t part_bstride;
+    int batch;
 };
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves);
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);

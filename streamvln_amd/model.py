@@ -226,13 +226,13 @@ class StreamVLNForCausalLM:
         _check(self._lib.svln_reset_env(self._h, env_idx))
 
     # ---- the call (stream_video_vln.py:353-407) -------------------------------------------------------
-    @torch.no_grad()
-    def generate(self, inputs=None, images=None, image_sizes=None, depths=None, poses=None, intrinsics=None, task_ids=None,
-                 **kwargs):
-        kwargs.pop("position_ids", None)
-        kwargs.pop("attention_mask", None)
+    def _parse_call(self, inputs, images, kwargs):
+        """argument handling shared by generate / generate_batch; returns (ids, pixels [V,3,S,S] fp32, V, n_memory, env_id, past,
+        max_new, eos)"""
+        kwargs = dict(kwargs)
+        for k in ("position_ids", "attention_mask", "task_type", "image_sizes", "depths", "poses", "intrinsics", "task_ids"):
+            kwargs.pop(k, None)
         time_ids = kwargs.pop("time_ids", None)
-        kwargs.pop("task_type", None)
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")
         env_id = kwargs.pop("env_id", None)
@@ -248,14 +248,13 @@ class StreamVLNForCausalLM:
             raise NotImplementedError("text-only turns are not part of the streaming path")
         if env_id is None or not (0 <= env_id < len(self.curr_t)):
             raise IndexError(f"env_id {env_id} out of range")
-
         ids = torch.as_tensor(inputs).reshape(-1).to("cpu", torch.int64)
         if ids.numel() == 1:
             raise NotImplementedError("single-token `inputs` bypasses the multimodal path in the reference "
                                       "(stream_video_vln.py:149)")
         B, V = images.shape[0], images.shape[1]
         if B != 1:
-            raise NotImplementedError("one env per generate call (reference harnesses run batch 1)")
+            raise NotImplementedError("one env per request (reference harnesses run batch 1); use generate_batch for several envs")
         n_memory = 0
         if V != 1:                                            # encode_rgbd, stream_video_vln.py:111-130
             start_idx = time_ids[0][0] if (time_ids is not None and time_ids[0] is not None) else 0
@@ -264,23 +263,37 @@ class StreamVLNForCausalLM:
                     raise TypeError("model.num_history must be set before a <memory> turn")
                 n_memory = int(self.model.num_history)
         pix = images[0].to(torch.float32).contiguous()
-        on_dev = int(pix.is_cuda)
-        if on_dev:
-            torch.cuda.synchronize(pix.device)
-        _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+        return ids, pix, V, n_memory, env_id, past, max_new, eos
 
+    def _begin_turn(self, env_id, past):
+        """KV handle / per-env embeds bookkeeping of StreamVLNForCausalLM.generate (stream_video_vln.py:396-401)"""
         if past is None:
             _check(self._lib.svln_kv_reset(self._h, env_id))
-        else:
-            if not isinstance(past, KVHandle) or past.env_id != env_id or past.epoch != self._epoch[env_id]:
-                raise ValueError("past_key_values does not belong to this env's current window")
-        if self.curr_t[env_id] == 0:                          # stream_video_vln.py:397-400
+        elif not isinstance(past, KVHandle) or past.env_id != env_id or past.epoch != self._epoch[env_id]:
+            raise ValueError("past_key_values does not belong to this env's current window")
+        if self.curr_t[env_id] == 0:
             ne, kl = C.c_int32(), C.c_int32()
             _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
             if ne.value != 0:
                 _check(self._lib.svln_reset_env(self._h, env_id))
         self.curr_t[env_id] += 1
 
+    def _result(self, env_id, tokens, inputs):
+        ne, kl = C.c_int32(), C.c_int32()
+        _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+        dev = inputs.device if isinstance(inputs, torch.Tensor) else "cpu"
+        seq = torch.from_numpy(np.asarray(tokens, dtype=np.int64).copy()).unsqueeze(0).to(dev)
+        return GenerateOutput(sequences=seq, past_key_values=KVHandle(env_id, self._epoch[env_id], kl.value))
+
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, image_sizes=None, depths=None, poses=None, intrinsics=None, task_ids=None,
+                 **kwargs):
+        ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
+        on_dev = int(pix.is_cuda)
+        if on_dev:
+            torch.cuda.synchronize(pix.device)
+        _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+        self._begin_turn(env_id, past)
         ids_np = np.ascontiguousarray(ids.numpy())
         _check(self._lib.svln_append_turn(self._h, env_id, ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
         cap = min(max_new, self.cfg.max_positions)
@@ -289,11 +302,64 @@ class StreamVLNForCausalLM:
         eos_np = np.asarray(eos, dtype=np.int64)
         _check(self._lib.svln_generate(self._h, env_id, max_new, eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
                                        out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n_out)))
-        ne, kl = C.c_int32(), C.c_int32()
-        _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
-        dev = inputs.device if isinstance(inputs, torch.Tensor) else "cpu"
-        seq = torch.from_numpy(out[: n_out.value].copy()).unsqueeze(0).to(dev)
-        return GenerateOutput(sequences=seq, past_key_values=KVHandle(env_id, self._epoch[env_id], kl.value))
+        return self._result(env_id, out[: n_out.value], inputs)
+
+    @torch.no_grad()
+    def generate_batch(self, requests, max_new_tokens: int = 10000, eos_token_ids=None):
+        """Several envs' turns executed together (build-side extension, SURVEY.md 8f-1 / BASELINE configs[4]).
+        `requests`: list of kwargs dicts as passed to `generate` (distinct env_id, at most 8).  Per-env results are those of
+        `generate` called env by env (same protocol, same KV / embeds state); the dense layers and every decode step run
+        once for the whole batch.  Returns a list of GenerateOutput in request order."""
+        if not (1 <= len(requests) <= 8):
+            raise ValueError("1..8 requests per batch")
+        parsed = []
+        for r in requests:
+            r = dict(r)
+            r.setdefault("max_new_tokens", max_new_tokens)
+            if eos_token_ids is not None:
+                r.setdefault("eos_token_ids", eos_token_ids)
+            parsed.append((r,) + self._parse_call(r.pop("inputs", None), r.pop("images", None), r))
+        if len({p[5] for p in parsed}) != len(parsed):
+            raise ValueError("duplicate env_id in batch")
+        max_new, eos = parsed[0][7], parsed[0][8]
+        if any(p[7] != max_new or p[8] != eos for p in parsed):
+            raise ValueError("max_new_tokens / eos_token_ids must be the same for every request of a batch")
+        # vision: encode the frames of as many requests as fit the frame buffer per call, then splice per env
+        i = 0
+        while i < len(parsed):
+            j, frames = i, 0
+            while j < len(parsed) and (j == i or frames + parsed[j][3] <= self.max_frames):
+                frames += parsed[j][3]
+                j += 1
+            if frames > self.max_frames:
+                raise ValueError(f"a request has {frames} frames but the engine was built with max_frames={self.max_frames}")
+            pix = torch.cat([p[2] for p in parsed[i:j]], 0).contiguous()
+            on_dev = int(pix.is_cuda)
+            if on_dev:
+                torch.cuda.synchronize(pix.device)
+            _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), frames, on_dev))
+            base = 0
+            for (_, ids, _, V, n_memory, env_id, past, _, _) in parsed[i:j]:
+                self._begin_turn(env_id, past)
+                ids_np = np.ascontiguousarray(ids.numpy())
+                _check(self._lib.svln_append_turn_at(self._h, env_id, ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, base, n_memory))
+                base += V
+            i = j
+        envs = np.asarray([p[5] for p in parsed], dtype=np.int32)
+        cap = min(max_new, self.cfg.max_positions)
+        out = np.zeros((len(parsed), cap), dtype=np.int64)
+        n_out = np.zeros(len(parsed), dtype=np.int32)
+        eos_np = np.asarray(eos, dtype=np.int64)
+        _check(self._lib.svln_generate_batch(self._h, envs.ctypes.data_as(C.POINTER(C.c_int32)), len(parsed), max_new,
+                                             eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
+                                             out.ctypes.data_as(C.POINTER(C.c_int64)), cap, n_out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return [self._result(p[5], out[k, : n_out[k]], requests[k].get("inputs")) for k, p in enumerate(parsed)]
+
+    def last_hidden_batch(self, slot: int) -> np.ndarray:
+        buf = np.empty((8, self.cfg.hidden), dtype=np.float32)
+        n = C.c_int32()
+        _check(self._lib.svln_get_hidden_batch(self._h, slot, buf.ctypes.data_as(C.POINTER(C.c_float)), 8, C.byref(n)))
+        return buf[: n.value].copy()
 
     # ---- parity taps (tests) / perf helpers (bench) ---------------------------------------------------
     def last_hidden(self) -> np.ndarray:

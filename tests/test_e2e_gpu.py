@@ -348,3 +348,62 @@ def test_from_pretrained_safetensors_equals_synthetic(tmp_path):
     with pytest.raises(Exception):
         StreamVLNForCausalLM.from_pretrained(str(tmp_path / "missing"), config=cfg)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_lockstep_envs_equal_solo_runs(dtype):
+    """BASELINE configs[4] (concurrent envs on one GPU, build-side extension): 5 envs stepped in lockstep through
+    `generate_batch` (batched prefill rows, batched decode steps, padded to 8 slots, grouped frame encodes incl. a <memory>
+    window restart) reproduce the ids every env gets from the batch-1 path; fp32: hidden within 1e-3."""
+    from streamvln_amd.agent import BatchedAgents, StreamingAgent
+    from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+    sc = SCENARIOS["tiny_episode"]
+    cfg, n_env, steps = sc["cfg"], 5, 16
+    m = StreamVLNForCausalLM(cfg, dtype=dtype, max_envs=n_env, max_frames=7, max_positions=2048)
+    m.load_synthetic(SEED)
+    m.model.num_history = sc["num_history"]
+    pre = m.get_vision_tower().image_processor.preprocess_array
+    eos = eos_ids(sc)
+
+    def make(e):
+        enc = SyntheticPromptEncoder(cfg, seed=100 + e, first_len=40, memory_len=48, later_len=16)
+        return StreamingAgent(m, enc, num_frames=sc["num_frames"], num_future_steps=4, num_history=sc["num_history"], env_id=e,
+                              device="cuda", max_new_tokens=sc["max_new"], eos_token_ids=eos, preprocess=pre)
+    solo, solo_hid = [], []
+    for e in range(n_env):
+        ag, hid = make(e), []
+        for s in range(steps):
+            n0 = len(ag.turn_log)
+            ag.act(synthetic_frame(e, s))
+            if len(ag.turn_log) > n0:
+                hid.append(m.last_hidden())
+        solo.append([t["out"].sequences[0].tolist() for t in ag.turn_log])
+        solo_hid.append(hid)
+    m.reset(n_env)
+    agents = [make(e) for e in range(n_env)]
+    batch = BatchedAgents(agents)
+    bat_hid = [[] for _ in range(n_env)]
+    for s in range(steps):
+        n0 = len(agents[0].turn_log)
+        batch.act([synthetic_frame(e, s) for e in range(n_env)])
+        if len(agents[0].turn_log) > n0:
+            for e in range(n_env):
+                bat_hid[e].append(m.last_hidden_batch(e))
+    agree = total = 0
+    for e in range(n_env):
+        got = [t["out"].sequences[0].tolist() for t in agents[e].turn_log]
+        assert len(got) == len(solo[e]) == 4 and [t["views"] for t in agents[e].turn_log] == [1, 1, 1, 3]
+        for t in range(4):
+            if dtype == torch.float32:
+                assert got[t] == solo[e][t], (e, t, got[t], solo[e][t])
+                assert np.abs(bat_hid[e][t] - solo_hid[e][t]).max() <= HIDDEN_TOL, (e, t)
+            else:
+                total += 1
+                agree += int(got[t][0] == solo[e][t][0])
+                rel = np.linalg.norm(bat_hid[e][t][0] - solo_hid[e][t][0]) / np.linalg.norm(solo_hid[e][t][0])
+                assert rel < 3e-2, (e, t, rel)
+    assert dtype == torch.float32 or agree >= total - 2, (agree, total)
+    with pytest.raises(ValueError):
+        req = agents[0]._build_request("")
+        m.generate_batch([req, dict(req)])                      # duplicate env
+    m.close()
