@@ -694,7 +694,7 @@ public:
     void head_batched(const T* rows, int B) {
         launch_rmsnorm<T>(st, rows, final_norm, xn, B, H, c.rms_eps);
         launch_gemv_batched<T>(st, gemvb_args(lm_head, H, xn, H, nullptr, nullptr, nullptr, 0, nullptr, 0, V, H, EPI_ARGMAX, B));
-        launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(V, EPI_ARGMAX), B, d_tok_b);
+        launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(V, EPI_ARGMAX, B), B, d_tok_b);
     }
     // One decode step for B envs (B in {1,2,4,8}; d_slots / d_tok_b already set): every weight matrix is streamed once.
     void decode_ops_batched(int B) {
@@ -702,14 +702,18 @@ public:
         launch_gather_rows<T>(st, d_tok_b, embed, feats, x, B, H);
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
-            launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, x, H, L.in_norm, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
+            // RMSNorm as its own tiny launch in the batched step (amortised over B envs): the GEMVs then run packed bf16 dot
+            // products on the raw activation chunks
+            launch_rmsnorm<T>(st, x, L.in_norm, xn, B, H, c.rms_eps);
+            launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
             AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, qd, 1, 0, 0, true);
             a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr;
             a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * 130;
             launch_attention<T>(st, a, 128, 1);
             launch_attention_combine<T>(st, a, 128);
             launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));
-            launch_gemv_batched<T>(st, gemvb_args(L.gu_w, H, x, H, L.post_norm, nullptr, nullptr, 0, hbuf, I, 2 * I, H, EPI_SWIGLU, B));
+            launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
+            launch_gemv_batched<T>(st, gemvb_args(L.gu_w, H, xn, H, nullptr, nullptr, nullptr, 0, hbuf, I, 2 * I, H, EPI_SWIGLU, B));
             launch_gemv_batched<T>(st, gemvb_args(L.down_w, I, hbuf, I, nullptr, nullptr, x, H, x, H, H, I, EPI_NONE, B));
         }
         head_batched(x, B);

@@ -20,6 +20,7 @@ namespace svln {
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_WAVES = GEMV_THREADS / 64;
 
@@ -208,24 +209,24 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_ksplit_kernel(GemvArgs p) {
 // 4 * B * 8 FMAs.  Partial sums (and the per-env sum of squares) are reduced across waves through LDS.
 template <typename T, int EPI, bool NORM, int B>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_batched_kernel(GemvBatchArgs p) {
-    constexpr int EPC = Elt<T>::PER_CHUNK, R = 4, STRIDE = 64 * GEMV_WAVES;
+    constexpr int EPC = Elt<T>::PER_CHUNK, R = 4, STRIDE = 64 * GEMV_WAVES;       // (R = 8 measured no better at B = 8: dot2-issue bound)
     __shared__ float part[GEMV_WAVES][R * B + B];
     const int nch = p.K / EPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
     const T* W = (const T*)p.W;
     const T* xg = (const T*)p.x;
     const T* gg = (const T*)p.norm_w;
-    const int n_units = EPI == EPI_SWIGLU ? p.N / 4 : (p.N + R - 1) / R;      // one unit = R weight rows
+    const int n_units = EPI == EPI_SWIGLU ? p.N / R : (p.N + R - 1) / R;      // one unit = R weight rows
     float best = -INFINITY;                                                   // EPI_ARGMAX: thread b < B tracks env b
     int best_i = 0x7FFFFFFF;
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const T* rows[R];
         int n0;
-        if (EPI == EPI_SWIGLU) {          // outputs j0, j0+1: rows gate j0, up j0, gate j0+1, up j0+1 of the [gate 32 | up 32] packing
-            const int j0 = u * 2;
+        if (EPI == EPI_SWIGLU) {          // outputs j0 .. j0+R/2-1: rows (gate j, up j) pairs of the [gate 32 | up 32] packing
+            const int j0 = u * (R / 2);
             n0 = j0;
 #pragma unroll
-            for (int o = 0; o < 2; ++o) {
+            for (int o = 0; o < R / 2; ++o) {
                 const size_t gr = (size_t)((j0 + o) >> 5) * 64 + ((j0 + o) & 31);
                 rows[2 * o] = W + gr * p.ldw;
                 rows[2 * o + 1] = W + (gr + 32) * p.ldw;
@@ -248,23 +249,39 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_batched_kernel(GemvBatchArg
             for (int r = 0; r < R; ++r) w[r] = load_nt(rows[r] + (size_t)ci * EPC);
 #pragma unroll
             for (int b = 0; b < B; ++b) xr[b] = *(const uint4*)(xg + (size_t)b * p.ldx + (size_t)ci * EPC);
-            float gf[EPC];
-            if (NORM) chunk_to_f32<T>(*(const uint4*)(gg + (size_t)ci * EPC), gf);
-            float wf[R][EPC];
+            if (sizeof(T) == 2 && !NORM) {
+                // bf16: packed dot products straight on the bf16 pairs (v_dot2c_f32_bf16), no conversions
 #pragma unroll
-            for (int r = 0; r < R; ++r) chunk_to_f32<T>(w[r], wf[r]);
+                for (int b = 0; b < B; ++b) {
+                    const unsigned xw[4] = {xr[b].x, xr[b].y, xr[b].z, xr[b].w};
 #pragma unroll
-            for (int b = 0; b < B; ++b) {
-                float xf[EPC];
-                chunk_to_f32<T>(xr[b], xf);
-                if (NORM) {
+                    for (int r = 0; r < R; ++r) {
+                        const unsigned ww[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) { ss[b] = fmaf(xf[e], xf[e], ss[b]); xf[e] *= gf[e]; }
+                        for (int q = 0; q < 4; ++q)
+                            acc[r][b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ww[q]), __builtin_bit_cast(bf16x2_t, xw[q]),
+                                                                        acc[r][b], false);
+                    }
                 }
+            } else {
+                float gf[EPC];
+                if (NORM) chunk_to_f32<T>(*(const uint4*)(gg + (size_t)ci * EPC), gf);
+                float wf[R][EPC];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                for (int r = 0; r < R; ++r) chunk_to_f32<T>(w[r], wf[r]);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[r][b] = fmaf(wf[r][e], xf[e], acc[r][b]);
+                for (int b = 0; b < B; ++b) {
+                    float xf[EPC];
+                    chunk_to_f32<T>(xr[b], xf);
+                    if (NORM) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) { ss[b] = fmaf(xf[e], xf[e], ss[b]); xf[e] *= gf[e]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) acc[r][b] = fmaf(wf[r][e], xf[e], acc[r][b]);
+                }
             }
         }
 #pragma unroll
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_batched_kernel(GemvBatchArg
         __syncthreads();
         auto total = [&](int k) { return part[0][k] + part[1][k] + part[2][k] + part[3][k]; };
         if (EPI == EPI_SWIGLU) {
-            if (tid < 2 * B) {
+            if (tid < (R / 2) * B) {
                 const int o = tid / B, b = tid % B;
                 const float sc = NORM ? rsqrtf(total(R * B + b) / (float)p.K + p.eps) : 1.0f;
                 const float gt = total((2 * o) * B + b) * sc, up = total((2 * o + 1) * B + b) * sc;
@@ -490,12 +507,14 @@ template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, h
     }
 }
 #undef SVLN_LAUNCH
-int gemv_batched_grid(int N, int epi) {
-    const int units = epi == EPI_SWIGLU ? N / 4 : (N + 3) / 4;
+int gemv_batched_grid(int N, int epi, int B) {
+    const int R = 4;
+    (void)B;
+    const int units = epi == EPI_SWIGLU ? N / R : (N + R - 1) / R;
     return units < 2048 ? (units < 1 ? 1 : units) : 2048;
 }
 template <typename T, int EPI, bool NORM> static void launch_gb(hipStream_t s, const GemvBatchArgs& a) {
-    dim3 g(gemv_batched_grid(a.N, EPI)), b(GEMV_THREADS);
+    dim3 g(gemv_batched_grid(a.N, EPI, a.B)), b(GEMV_THREADS);
     switch (a.B) {
         case 1: hipLaunchKernelGGL((gemv_batched_kernel<T, EPI, NORM, 1>), g, b, 0, s, a); break;
         case 2: hipLaunchKernelGGL((gemv_batched_kernel<T, EPI, NORM, 2>), g, b, 0, s, a); break;

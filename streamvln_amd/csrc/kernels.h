@@ -46,7 +46,7 @@ template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, h
 int gemv_grid(int N);                       // workgroups launch_gemv uses for N rows
 
 // B (1, 2, 4 or 8) activation vectors against one weight stream: x [B][ldx], y [B][ldy], res [B][ldr].
-// EPI_ARGMAX: part_val / part_idx are [B][gemv_batched_grid(N, epi)]; launch_argmax_final_batched reduces them to B tokens.
+// EPI_ARGMAX: part_val / part_idx are [B][gemv_batched_grid(N, epi, B)]; launch_argmax_final_batched reduces them to B tokens.
 struct GemvBatchArgs {
     const void* W; int ldw;
     const void* x; int ldx;
@@ -58,7 +58,7 @@ struct GemvBatchArgs {
     float* part_val; int* part_idx;
 };
 template <typename T> void launch_gemv_batched(hipStream_t s, const GemvBatchArgs& a);
-int gemv_batched_grid(int N, int epi);
+int gemv_batched_grid(int N, int epi, int B);
 void launch_argmax_final_batched(hipStream_t s, const float* part_val, const int* part_idx, int n, int B, int* out_tokens);
 void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token,
                          float* out_top /*[2]: best, runner-up of partial maxima (diagnostic)*/);
