@@ -36,11 +36,13 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_> 
     static constexpr int SH = ROWS_PER_BANKROW == 2 ? 1 : 2;
     static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     static constexpr int A_LOADS = BM * CH / THREADS, W_LOADS = BN * CH / THREADS;
-    static_assert(BM / WM == 64 && BN / WN == 64, "each wave owns 64x64");
+    static constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;   // 32x32 accumulator tiles per wave
+    static_assert(BM / WM % 32 == 0 && BN / WN == 64, "wave tile: rows a multiple of 32, 64 columns ([gate 32 | up 32] for SwiGLU)");
     static_assert(BM * CH % THREADS == 0 && BN * CH % THREADS == 0, "staging must divide evenly");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
+using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2>;       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
 
@@ -307,11 +309,13 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
 
-    f32x16 acc[2][2];
+    constexpr int MI = C::MI, NJ = C::NJ, STEPS = C::CH / 2, RD = MI + NJ;     // fragment reads per macro step
+    constexpr int WROWS = C::BM / C::WM;
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -319,39 +323,50 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     // LDS-DMA (it emits s_waitcnt vmcnt(0) before the first ds_read of the stage, draining the ring); the asm reads are
     // ordered by our own protocol instead (counted vmcnt + barrier above, lgkmcnt waits tied to the destinations below).
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned offA[C::CH / 2][2], offW[C::CH / 2][2];
+    unsigned offA[STEPS][MI], offW[STEPS][NJ];
 #pragma unroll
-    for (int s = 0; s < C::CH / 2; ++s)
+    for (int s = 0; s < STEPS; ++s) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ra_ = wr * 64 + i * 32 + r32, rw_ = wc * 64 + i * 32 + r32;
+        for (int i = 0; i < MI; ++i) {
+            const int ra_ = wr * WROWS + i * 32 + r32;
             offA[s][i] = lds0 + ra_ * C::ROWB + swz<C>(ra_, 2 * s + h);
-            offW[s][i] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
         }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int rw_ = wc * 64 + j * 32 + r32;
+            offW[s][j] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
+        }
+    }
+    // fragments double-buffered by macro step: the reads of step s+1 are in flight under the MFMAs of step s
+    u32x4 fa[2][MI], fb[2][NJ];
+    auto read_step = [&](int s, unsigned bo) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
+    };
+    auto wait_step = [&](int k, bool more) {          // step in buffer k landed (`more`: the next step's RD reads stay in flight)
+        if constexpr (MI == 4) {
+            if (more) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]) : "n"(RD));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]));
+        } else {
+            if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fb[k][0]), "+v"(fb[k][1]) : "n"(RD));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fb[k][0]), "+v"(fb[k][1]));
+        }
+    };
     auto compute = [&](int buf) {
         const unsigned bo = buf * C::STAGE_BYTES;
-        u32x4 fa[C::CH / 2][2], fb[C::CH / 2][2];
+        read_step(0, bo);
 #pragma unroll
-        for (int s = 0; s < C::CH / 2; ++s) {
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + 1 < STEPS) read_step(s + 1, bo);
+            wait_step(s & 1, s + 1 < STEPS);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][i]) : "v"(offA[s][i] + bo));
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][j]) : "v"(offW[s][j] + bo));
-        }
-#pragma unroll
-        for (int s = 0; s < C::CH / 2; ++s) {
-            // reads return in order: all but the (CH/2 - 1 - s) * 4 youngest have landed
-            if (s == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]));
-            if (s == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
-            if (s == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fb[2][0]), "+v"(fb[2][1]));
-            if (s == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb[3][0]), "+v"(fb[3][1]));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint4 av = make_uint4(fa[s][i].x, fa[s][i].y, fa[s][i].z, fa[s][i].w);
-                    const uint4 bv = make_uint4(fb[s][j].x, fb[s][j].y, fb[s][j].z, fb[s][j].w);
-                    mma_chunk<T>(av, bv, acc[i][j]);
+                for (int j = 0; j < NJ; ++j) {
+                    const u32x4 a4 = fa[s & 1][i], b4 = fb[s & 1][j];
+                    mma_chunk<T>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
                 }
             __builtin_amdgcn_sched_barrier(0);      // keep step s's MFMAs ahead of step s+1's wait
         }
@@ -374,14 +389,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     if (SPLITK) {
         float* slab = p.ws + (size_t)ks * p.M * p.N;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int nn = col0 + wc * 64 + j * 32 + r32;
                 if (nn >= p.N) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                    const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
                     if (m < p.M) slab[(size_t)m * p.N + nn] = acc[i][j][r];
                 }
             }
@@ -394,24 +409,24 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         const int n_out = ((col0 + wc * 64) >> 1) + r32;
         const bool ok_n = (col0 + wc * 64 + 32 + r32) < p.N;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
                 if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][0][r]) * acc[i][1][r]);
             }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int nn = col0 + wc * 64 + j * 32 + r32;
             if (nn >= p.N) continue;
             const float bv = bias ? to_f32(bias[nn]) : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
+                const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
                 if (m >= p.M) continue;
                 float v = epi_act<T, EPI>(acc[i][j][r] + bv);
                 if (res) {
@@ -508,6 +523,16 @@ template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
     //   M <= 256            -> 256x128 tiles + split-K: one row tile, every weight byte staged once
     //   M  > 256, >= 96 tiles of 128x128 -> 128x128 tiles, no split (2 workgroups per CU overlap each other's phases)
     //   otherwise (few tiles, long K: ViT fc2, o/down at T = 376) -> 256x128 tiles + split-K
+    //   large M AND N (>= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
+    //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel
+    const int tilesbig = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    static const int big_min = [] { const char* e = getenv("SVLN_GEMM_BIG_MIN"); return e ? atoi(e) : 256; }();   // tuning knob
+    if ((tilesbig >= big_min && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
+        a.nsplit = 1;
+        a.launch_tiles = tilesbig;
+        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CfgBig, false>), dim3(tilesbig), dim3(CfgBig::THREADS), CfgBig::NBUF * CfgBig::STAGE_BYTES, s, a);
+        return;
+    }
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     const bool want128 = a.M > 256 && tiles128 >= 96;
     if ((want128 && a.force_split == 0) || (a.force_cfg & 0xFFF) == 128) {
@@ -573,6 +598,7 @@ template <typename T, int EPI> static void gemm_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128::NBUF * Cfg128::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::NBUF * CfgBig::STAGE_BYTES);
 }
 void gemm_init_attrs() {
     gemm_attr<bf16, EPI_NONE>(); gemm_attr<bf16, EPI_GELU_TANH>(); gemm_attr<bf16, EPI_GELU_ERF>(); gemm_attr<bf16, EPI_SWIGLU>();

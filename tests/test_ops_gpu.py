@@ -31,7 +31,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2)])   # 0x2000 = register-staged kernel
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -79,7 +79,7 @@ def test_gemm_swiglu_and_posmod(dtype):
     torch.cuda.synchronize()
     chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU, 0, 0))
     assert_close(out, exp, dtype, "gemm swiglu")
-    for cs in [(128, 0), (0, 1), (0, 4)]:
+    for cs in [(128, 0), (0, 1), (0, 4), (256, 0)]:
         out.zero_()
         torch.cuda.synchronize()
         chk(m._lib.svln_op_gemm(m._h, ptr(dA), K, ptr(dW), K, ptr(out), I, None, None, 0, 0, M, 2 * I, K, _lib.EPI_SWIGLU, *cs))
