@@ -69,7 +69,7 @@ struct EngineBase {
     virtual void phase_times(double* v, double* p, double* d, int reset) = 0;
     virtual void set_feature_cache(int cap) = 0;
     virtual void feature_cache_stats(int64_t* hits, int64_t* misses) = 0;
-    virtual void op_gemm(const GemmArgs& a) = 0;
+    virtual bool op_gemm(const GemmArgs& a) = 0;
     virtual void op_gemv(GemvArgs a, int32_t* host_token) = 0;
     virtual void op_rmsnorm(const void* x, const void* g, void* y, int rows, int n, float eps) = 0;
     virtual void op_layernorm(const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) = 0;
@@ -384,7 +384,7 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; return a;
+        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -566,9 +566,10 @@ public:
         const int qd = nq * 128;
         for (const Seg& g : segs)
             HIP_CHECK(hipMemcpyAsync(x + (size_t)g.off * H, g.e->embeds + (size_t)g.P * H, (size_t)g.Tn * H * sizeof(T), hipMemcpyDeviceToDevice, st));
+        bool xn_ready = false;        // xn already holds rmsnorm(x) * in_norm (written by the previous layer's down_proj epilogue)
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
-            launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
+            if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
             launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE));
             for (const Seg& g : segs) {
                 T* q_g = qkv + (size_t)g.off * qkv_dim;
@@ -579,10 +580,14 @@ public:
                 launch_attention<T>(st, a, 128, 4);
                 if (a.nsplit > 1) launch_attention_combine<T>(st, a, 128);
             }
-            launch_gemm<T>(st, gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE));
-            launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
+            // the split-K reduce of o_proj / down_proj also emits the following RMSNorm when it can (T <= 256 rows)
+            GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE);
+            ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
+            if (!launch_gemm<T>(st, ao)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
             launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU));
-            launch_gemm<T>(st, gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE));
+            GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE);
+            if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
+            xn_ready = launch_gemm<T>(st, ad);
         }
     }
     void prefill(Env& e, int P, int Tn) {
@@ -918,7 +923,12 @@ public:
     }
 
     // ------------------------------------------------------------------------------- op-level entry points
-    void op_gemm(const GemmArgs& a0) override { GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.zeros = zero_line; launch_gemm<T>(st, a); sync(); }
+    bool op_gemm(const GemmArgs& a0) override {
+        GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.zeros = zero_line;
+        const bool fused = launch_gemm<T>(st, a);
+        sync();
+        return fused;
+    }
     void op_gemv(GemvArgs a, int32_t* host_token) override {
         a.part_val = part_val; a.part_idx = part_idx;
         launch_gemv<T>(st, a);
@@ -1037,9 +1047,20 @@ int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses) { A
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                  int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split) {
     API_BEGIN
-    GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
-    a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = nullptr; a.ws_elems = 0; a.nsplit = 1; a.zeros = nullptr; a.force_cfg = force_cfg; a.force_split = force_split;
+    GemmArgs a; std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.nsplit = 1; a.force_cfg = force_cfg; a.force_split = force_split;
     h->impl->op_gemm(a);
+    API_END
+}
+int svln_op_gemm_rmsnorm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr, const void* norm_w,
+                         void* norm_out, float eps, int M, int N, int K, int force_split, int* fused) {
+    API_BEGIN
+    GemmArgs a; std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.res = res; a.ldr = ldr;
+    a.M = M; a.N = N; a.K = K; a.epi = EPI_NONE; a.nsplit = 1; a.force_split = force_split; a.norm_w = norm_w; a.norm_out = norm_out; a.norm_eps = eps;
+    const bool f = h->impl->op_gemm(a);
+    if (fused) *fused = f ? 1 : 0;
     API_END
 }
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res, void* y,

@@ -495,6 +495,54 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
     }
 }
 
+// Split-K reduce of one output row per workgroup (+ bias + residual), fused with the RMSNorm of the finished row:
+//   C[m] = round(sum_s slab[s][m] + bias + res[m]);   Y[m] = g * (C[m] * rsqrt(mean(C[m]^2) + eps))      (N <= 4096, N % 4 == 0)
+// Same arithmetic as splitk_epilogue_kernel<EPI_NONE> followed by rmsnorm_kernel on the rounded row.
+template <typename T>
+__global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x, n0 = tid * 4;      // one thread = 4 consecutive columns of the row
+    const size_t slab = (size_t)p.M * p.N;
+    T* Cc = (T*)p.C;
+    const T* bias = (const T*)p.bias;
+    const T* res = (const T*)p.res;
+    const T* g = (const T*)p.norm_w;
+    T* Y = (T*)p.norm_out;
+    const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+    const bool live = n0 < p.N;
+    float v[4] = {0, 0, 0, 0};
+    float ss = 0.0f;
+    if (live) {
+        float a[4] = {0, 0, 0, 0};
+        const float* src = p.ws + (size_t)m * p.N + n0;
+#pragma unroll 4
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float4 t = *(const float4*)(src + s * slab);
+            a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = a[e] + (bias ? to_f32(bias[n0 + e]) : 0.0f);
+            if (res) x += to_f32(res[(size_t)rr * p.ldr + n0 + e]);
+            const T t = from_f32<T>(x);
+            Cc[(size_t)m * p.ldc + n0 + e] = t;
+            v[e] = to_f32(t);
+            ss = fmaf(v[e], v[e], ss);
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float sc = rsqrtf(tot / (float)p.N + p.norm_eps);
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Y[(size_t)m * p.N + n0 + e] = from_f32<T>(to_f32(g[n0 + e]) * (v[e] * sc));
+    }
+}
+
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
@@ -504,19 +552,24 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
 }
 
-template <typename T, int EPI> void launch_split(hipStream_t s, GemmArgs a, int S) {
+template <typename T, int EPI> bool launch_split(hipStream_t s, GemmArgs a, int S) {
     a.nsplit = S;
     launch_cfg<T, EPI, Cfg256, true>(s, a, S);
+    if (EPI == EPI_NONE && a.norm_out && a.norm_w && a.tile_base == 0 && a.N <= 4096 && a.N % 4 == 0) {
+        hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(1024), 0, s, a);
+        return true;
+    }
     const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
     const int n_begin = EPI == EPI_SWIGLU ? a.tile_base * (Cfg256::BN / 2) : a.tile_base * Cfg256::BN;
     const size_t work = (size_t)a.M * ((n_out - n_begin) / 4 + 1);
     int grid = (int)((work + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, a);
+    return false;
 }
 
-template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
-    if (a.M <= 0 || a.N <= 0) return;
+template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
+    if (a.M <= 0 || a.N <= 0) return false;
     constexpr int EPC = Elt<T>::PER_CHUNK;
     a.tile_base = 0;
     // Tile choice (measured on MI355X, tools/kbench.py):
@@ -531,7 +584,7 @@ template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
         a.nsplit = 1;
         a.launch_tiles = tilesbig;
         hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CfgBig, false>), dim3(tilesbig), dim3(CfgBig::THREADS), CfgBig::NBUF * CfgBig::STAGE_BYTES, s, a);
-        return;
+        return false;
     }
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     const bool want128 = a.M > 256 && tiles128 >= 96;
@@ -539,7 +592,7 @@ template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
         a.nsplit = 1;
         a.launch_tiles = tiles128;
         launch_cfg<T, EPI, Cfg128, false>(s, a, 1);
-        return;
+        return false;
     }
     // 256x128 tiles: ONE workgroup is resident per CU (144 KiB LDS ring), so workgroup counts are quantised in rounds
     // of 256.  Pick the K split that fills one round (tiles * S <= 256); when a single row tile has between 256 and 512
@@ -561,8 +614,8 @@ template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
     if (a.force_split > 0) {
         a.launch_tiles = tiles256;
         if (a.force_split == 1) { a.nsplit = 1; launch_cfg<T, EPI, Cfg256, false>(s, a, 1); }
-        else launch_split<T, EPI>(s, a, a.force_split);
-        return;
+        else return launch_split<T, EPI>(s, a, a.force_split);
+        return false;
     }
     if (tiles_m == 1 && tiles_n > 256 && tiles_n < 512 && can_split && pick(tiles_n - 256) > 1) {
         a.nsplit = 1;
@@ -571,24 +624,25 @@ template <typename T, int EPI> void launch_epi(hipStream_t s, GemmArgs a) {
         a.tile_base = 256;
         a.launch_tiles = tiles_n - 256;
         launch_split<T, EPI>(s, a, pick(tiles_n - 256));
-        return;
+        return false;
     }
     a.launch_tiles = tiles256;
     const int S = pick(tiles256);
-    if (S <= 1) { a.nsplit = 1; launch_cfg<T, EPI, Cfg256, false>(s, a, 1); }
-    else launch_split<T, EPI>(s, a, S);
+    if (S <= 1) { a.nsplit = 1; launch_cfg<T, EPI, Cfg256, false>(s, a, 1); return false; }
+    return launch_split<T, EPI>(s, a, S);
 }
 
 }  // namespace
 
-template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a) {
+template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a) {
     switch (a.epi) {
-        case EPI_NONE: launch_epi<T, EPI_NONE>(s, a); break;
-        case EPI_GELU_TANH: launch_epi<T, EPI_GELU_TANH>(s, a); break;
-        case EPI_GELU_ERF: launch_epi<T, EPI_GELU_ERF>(s, a); break;
-        case EPI_SWIGLU: launch_epi<T, EPI_SWIGLU>(s, a); break;
+        case EPI_NONE: return launch_epi<T, EPI_NONE>(s, a);
+        case EPI_GELU_TANH: return launch_epi<T, EPI_GELU_TANH>(s, a);
+        case EPI_GELU_ERF: return launch_epi<T, EPI_GELU_ERF>(s, a);
+        case EPI_SWIGLU: return launch_epi<T, EPI_SWIGLU>(s, a);
         default: break;
     }
+    return false;
 }
 
 template <typename T, int EPI> static void gemm_attr() {
@@ -604,7 +658,7 @@ void gemm_init_attrs() {
     gemm_attr<bf16, EPI_NONE>(); gemm_attr<bf16, EPI_GELU_TANH>(); gemm_attr<bf16, EPI_GELU_ERF>(); gemm_attr<bf16, EPI_SWIGLU>();
     gemm_attr<float, EPI_NONE>(); gemm_attr<float, EPI_GELU_TANH>(); gemm_attr<float, EPI_GELU_ERF>(); gemm_attr<float, EPI_SWIGLU>();
 }
-template void launch_gemm<bf16>(hipStream_t, const GemmArgs&);
-template void launch_gemm<float>(hipStream_t, const GemmArgs&);
+template bool launch_gemm<bf16>(hipStream_t, const GemmArgs&);
+template bool launch_gemm<float>(hipStream_t, const GemmArgs&);
 
 }  // namespace svln

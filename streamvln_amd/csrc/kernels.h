@@ -23,9 +23,13 @@ struct GemmArgs {
     float* ws; size_t ws_elems;   // split-K slab workspace (fp32) or null
     int nsplit, tile_base, launch_tiles;   // filled by the launcher (K splits; first column tile and tile count of this launch)
     const void* zeros;            // >= 16 B of zeros in device memory (K-tail source of the LDS-DMA path); null -> register-staged kernel
+    // optional fused RMSNorm of the finished output rows (o_proj -> post_attention_layernorm, down_proj -> next input_layernorm):
+    // when the product takes the split-K path with N <= 4096 the slab reduce also writes norm_out = rmsnorm(C) * norm_w and
+    // launch_gemm returns true; otherwise norm_out is untouched (false) and the caller runs launch_rmsnorm itself
+    const void* norm_w; void* norm_out; float norm_eps;
     int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
-template <typename T> void launch_gemm(hipStream_t s, const GemmArgs& a);
+template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced
 
 // y[N] = epi(W[N,K] . x'[K] + bias) + res,  x' = x or rmsnorm(x) * norm_w (fused prologue).
 // EPI_SWIGLU as above (y has N/2 entries).  EPI_ARGMAX: no y; per-workgroup (max, lowest index)

@@ -64,6 +64,38 @@ def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,split,expect_fused", [
+    (212, 512, 1024, 0, True),      # steady prefill rows: heuristic K split -> fused reduce + norm
+    (37, 3584, 3584, 4, True),      # o_proj at true width, ragged M
+    (212, 3584, 18944 // 8, 3, True),   # down_proj-like
+    (1, 512, 512, 2, True),
+    (700, 2048, 1024, 0, False),    # many 128x128 tiles -> unsplit: the caller must run the norm itself
+])
+def test_gemm_fused_rmsnorm(dtype, M, N, K, split, expect_fused):
+    """o_proj / down_proj + residual with the following RMSNorm emitted by the split-K reduce (modeling_qwen2.py:269-299)."""
+    import ctypes as C
+    m = engine(TINY, dtype)
+    A, Wt = q(rnd((M, K), 11), dtype), q(rnd((N, K), 12, 1.0 / math.sqrt(K)), dtype)
+    r, g = q(rnd((M, N), 13), dtype), q(1.0 + rnd((N,), 14, 0.2), dtype)
+    h = q(A @ Wt.t() + r, dtype)                       # the residual stream is stored in the engine dtype, the norm reads it back
+    exp_norm = O.rms_norm(h, g, 1e-6)
+    dA, dW, dg = A.to(dtype).cuda(), Wt.to(dtype).cuda(), g.to(dtype).cuda()
+    x = r.to(dtype).cuda()                             # in place: C == res, like the engine's residual stream
+    xn = torch.full((M, N), 7.0, dtype=dtype, device="cuda")
+    fused = C.c_int32(-1)
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm_rmsnorm(m._h, ptr(dA), K, ptr(dW), K, ptr(x), N, ptr(x), N, ptr(dg), ptr(xn), 1e-6, M, N, K, split, C.byref(fused)))
+    assert fused.value == int(expect_fused)
+    assert_close(x, A @ Wt.t() + r, dtype, f"gemm+res {M}x{N}x{K}")
+    if expect_fused:
+        if dtype == torch.bfloat16:                    # compare against the norm of the rows the kernel actually stored
+            exp_norm = O.rms_norm(x.float().cpu(), g, 1e-6)
+        assert_close(xn, exp_norm, dtype, f"fused rmsnorm {M}x{N}x{K}")
+    else:
+        assert float(xn.float().min()) == 7.0 and float(xn.float().max()) == 7.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_swiglu_and_posmod(dtype):
     m = engine(TINY, dtype)
     M, I, K = 150, 256, 512

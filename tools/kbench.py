@@ -35,23 +35,29 @@ def main():
             shapes = [tuple(int(v) for v in s.split(",")) for s in extra.split(";")]
         for (M, N, K, epi, fc, fs) in shapes:
             A = (torch.rand(M, K, device="cuda") - 0.5).to(dt)
-            W = ((torch.rand(N, K, device="cuda") - 0.5) * 0.05).to(dt)
+            # rotate over enough weight copies to exceed the 256 MB infinity cache: in the pipeline every layer's weights
+            # come cold from HBM (KBENCH_HOT=1 keeps one copy)
+            nw = 1 if os.environ.get("KBENCH_HOT") else max(1, min(8, -(-768 * 2**20 // (N * K * 2))))
+            Ws = [((torch.rand(N, K, device="cuda") - 0.5) * 0.05).to(dt) for _ in range(nw)]
             Cn = N // 2 if epi == _lib.EPI_SWIGLU else N
             out = torch.zeros(M, Cn, device="cuda", dtype=dt)
             torch.cuda.synchronize()
-            for _ in range(reps):
+            for i in range(reps):
+                W = Ws[i % nw]
                 _lib.check(lib.svln_op_gemm(h, ptr(A), K, ptr(W), K, ptr(out), Cn, None, None, 0, 0, M, N, K, epi, fc, fs))
     elif what == "gemv":
         for (N, K, norm, epi) in [(37888, 3584, True, _lib.EPI_SWIGLU), (4608, 3584, True, 0), (3584, 3584, False, 0),
                                   (3584, 18944, False, 0), (152064, 3584, False, _lib.EPI_ARGMAX)]:
-            W = ((torch.rand(N, K, device="cuda") - 0.5) * 0.05).to(dt)
+            nw = 1 if os.environ.get("KBENCH_HOT") else max(1, min(8, -(-768 * 2**20 // (N * K * 2))))
+            Ws = [((torch.rand(N, K, device="cuda") - 0.5) * 0.05).to(dt) for _ in range(nw)]
             x = (torch.rand(K, device="cuda") - 0.5).to(dt)
             g = torch.ones(K, device="cuda", dtype=dt) if norm else None
             y = torch.zeros(N, device="cuda", dtype=dt)
             import ctypes as C
             tok = C.c_int32()
             torch.cuda.synchronize()
-            for _ in range(reps):
+            for i in range(reps):
+                W = Ws[i % nw]
                 _lib.check(lib.svln_op_gemv(h, ptr(W), K, ptr(x), ptr(g), 1e-6, None, None, ptr(y), N, K, epi, C.byref(tok)))
     m.close()
 
