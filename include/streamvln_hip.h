@@ -104,11 +104,13 @@ int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses);
 /* force_cfg: 0 = heuristic, 128 = 128x128 tiles; force_split: 0 = heuristic, S >= 1 = 256x128 tiles with S K-splits */
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res,
                  int ldr, int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split);
-/* C = A . W^T + res, and -- when the product takes the split-K path (M <= 256 rows, N <= 4096) -- norm_out = rmsnorm(C) * norm_w from the
- * same slab reduce (*fused = 1); otherwise norm_out is left untouched (*fused = 0) and the caller runs svln_op_rmsnorm.  This is the
- * o_proj -> post_attention_layernorm / down_proj -> input_layernorm step of a prefill layer (modeling_qwen2.py:269-299). */
-int svln_op_gemm_rmsnorm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr,
-                         const void* norm_w, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
+/* C = A . W^T + bias + res, and -- when the product takes the split-K path (few rows, N <= 4096) -- norm_out = norm(C) from the same slab
+ * reduce (*fused = 1): RMSNorm with weight norm_w when norm_b is null (Qwen2 o_proj -> post_attention_layernorm, down_proj ->
+ * input_layernorm, modeling_qwen2.py:269-299), LayerNorm with weight norm_w and bias norm_b otherwise (SigLIP out_proj -> layer_norm2,
+ * fc2 -> next layer_norm1, siglip_encoder.py:269-305).  Otherwise norm_out is left untouched (*fused = 0) and the caller runs
+ * svln_op_rmsnorm / svln_op_layernorm. */
+int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
+                      const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
 int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps);

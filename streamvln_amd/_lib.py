@@ -59,7 +59,7 @@ SIGNATURES = {
     "svln_set_feature_cache": (_I, [_P, _I]),
     "svln_feature_cache_stats": (_I, [_P, _PI64, _PI64]),
     "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
-    "svln_op_gemm_rmsnorm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _I, _I, _PI32]),
+    "svln_op_gemm_norm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _PI32]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
     "svln_op_rmsnorm": (_I, [_P, _P, _P, _P, _I, _I, _F]),
     "svln_op_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),

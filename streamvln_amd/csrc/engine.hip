@@ -384,7 +384,7 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; return a;
+        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -410,15 +410,20 @@ public:
         // SigLipVisionEmbeddings (siglip_encoder.py:169-174): patch GEMM + bias + position embedding
         launch_patchify<T>(st, pixbuf, patches, F, c.v_image, c.v_patch, kp);
         launch_gemm<T>(st, gemm_args(patches, kp, patch_w, kp, vx, Hv, patch_b, pos_emb, Hv, S, M, Hv, kp, EPI_NONE));
+        bool vn_ready = false;                      // vn already holds ln1(vx) (written by the previous layer's fc2 epilogue)
         for (int i = 0; i < c.v_layers; ++i) {      // SigLipEncoderLayer (siglip_encoder.py:269-305)
             const VLayer& L = vl[i];
-            launch_layernorm<T>(st, vx, L.ln1_w, L.ln1_b, vn, M, Hv, c.v_eps);
+            if (!vn_ready) launch_layernorm<T>(st, vx, L.ln1_w, L.ln1_b, vn, M, Hv, c.v_eps);
             launch_gemm<T>(st, gemm_args(vn, Hv, L.qkv_w, Hv, vqkv, 3 * Hv, L.qkv_b, nullptr, 0, 0, M, 3 * Hv, Hv, EPI_NONE));
             vit_attention(vqkv, 3 * Hv, F, vattn, Hv);
-            launch_gemm<T>(st, gemm_args(vattn, Hv, L.out_w, Hv, vx, Hv, L.out_b, vx, Hv, 0, M, Hv, Hv, EPI_NONE));
-            launch_layernorm<T>(st, vx, L.ln2_w, L.ln2_b, vn, M, Hv, c.v_eps);
+            // out_proj / fc2 run split-K at one frame: their slab reduce also emits the following LayerNorm
+            GemmArgs ao = gemm_args(vattn, Hv, L.out_w, Hv, vx, Hv, L.out_b, vx, Hv, 0, M, Hv, Hv, EPI_NONE);
+            ao.norm_w = L.ln2_w; ao.norm_b = L.ln2_b; ao.norm_out = vn; ao.norm_eps = c.v_eps;
+            if (!launch_gemm<T>(st, ao)) launch_layernorm<T>(st, vx, L.ln2_w, L.ln2_b, vn, M, Hv, c.v_eps);
             launch_gemm<T>(st, gemm_args(vn, Hv, L.fc1_w, Hv, vh, Iv, L.fc1_b, nullptr, 0, 0, M, Iv, Hv, EPI_GELU_TANH));
-            launch_gemm<T>(st, gemm_args(vh, Iv, L.fc2_w, Iv, vx, Hv, L.fc2_b, vx, Hv, 0, M, Hv, Iv, EPI_NONE));
+            GemmArgs a2 = gemm_args(vh, Iv, L.fc2_w, Iv, vx, Hv, L.fc2_b, vx, Hv, 0, M, Hv, Iv, EPI_NONE);
+            if (i + 1 < c.v_layers) { a2.norm_w = vl[i + 1].ln1_w; a2.norm_b = vl[i + 1].ln1_b; a2.norm_out = vn; a2.norm_eps = c.v_eps; }
+            vn_ready = launch_gemm<T>(st, a2);
         }
         // mm_projector (builder.py:41-48) then get_2dPool bilinear 27x27 -> 14x14 (stream_video_vln.py:53-73)
         launch_gemm<T>(st, gemm_args(vx, Hv, proj0_w, Hv, proj_h, H, proj0_b, nullptr, 0, 0, M, H, Hv, EPI_GELU_ERF));
@@ -1053,11 +1058,11 @@ int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw,
     h->impl->op_gemm(a);
     API_END
 }
-int svln_op_gemm_rmsnorm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr, const void* norm_w,
-                         void* norm_out, float eps, int M, int N, int K, int force_split, int* fused) {
+int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
+                      const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused) {
     API_BEGIN
     GemmArgs a; std::memset(&a, 0, sizeof(a));
-    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.res = res; a.ldr = ldr;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.norm_b = norm_b;
     a.M = M; a.N = N; a.K = K; a.epi = EPI_NONE; a.nsplit = 1; a.force_split = force_split; a.norm_w = norm_w; a.norm_out = norm_out; a.norm_eps = eps;
     const bool f = h->impl->op_gemm(a);
     if (fused) *fused = f ? 1 : 0;

@@ -495,23 +495,27 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
     }
 }
 
-// Split-K reduce of one output row per workgroup (+ bias + residual), fused with the RMSNorm of the finished row:
-//   C[m] = round(sum_s slab[s][m] + bias + res[m]);   Y[m] = g * (C[m] * rsqrt(mean(C[m]^2) + eps))      (N <= 4096, N % 4 == 0)
-// Same arithmetic as splitk_epilogue_kernel<EPI_NONE> followed by rmsnorm_kernel on the rounded row.
+// Split-K reduce of one output row per workgroup (+ bias + residual), fused with the norm of the finished row:
+//   C[m] = round(sum_s slab[s][m] + bias + res[m]);
+//   Y[m] = g * (C[m] * rsqrt(mean(C[m]^2) + eps))                       (RMSNorm: Qwen2 post_attention / input_layernorm)
+//   Y[m] = (C[m] - mean) * rsqrt(var + eps) * g + b   when norm_b != 0   (LayerNorm: SigLIP ln2 / next layer's ln1)
+// N <= 4096, N % 4 == 0; blockDim = the row's quads rounded up to whole waves.  Same arithmetic as
+// splitk_epilogue_kernel<EPI_NONE> followed by rmsnorm_kernel / layernorm_kernel on the rounded row.
 template <typename T>
 __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
-    __shared__ float red[16];
-    const int m = blockIdx.x, tid = threadIdx.x, n0 = tid * 4;      // one thread = 4 consecutive columns of the row
+    __shared__ float red[2][16];
+    const int m = blockIdx.x, tid = threadIdx.x, n0 = tid * 4, nw = blockDim.x >> 6;      // one thread = 4 consecutive columns
     const size_t slab = (size_t)p.M * p.N;
     T* Cc = (T*)p.C;
     const T* bias = (const T*)p.bias;
     const T* res = (const T*)p.res;
     const T* g = (const T*)p.norm_w;
+    const T* nb = (const T*)p.norm_b;
     T* Y = (T*)p.norm_out;
     const int rr = p.res_mod > 0 ? m % p.res_mod : m;
     const bool live = n0 < p.N;
     float v[4] = {0, 0, 0, 0};
-    float ss = 0.0f;
+    float s1 = 0.0f;                 // sum (LayerNorm) or sum of squares (RMSNorm)
     if (live) {
         float a[4] = {0, 0, 0, 0};
         const float* src = p.ws + (size_t)m * p.N + n0;
@@ -527,19 +531,36 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
             const T t = from_f32<T>(x);
             Cc[(size_t)m * p.ldc + n0 + e] = t;
             v[e] = to_f32(t);
-            ss = fmaf(v[e], v[e], ss);
+            s1 = nb ? s1 + v[e] : fmaf(v[e], v[e], s1);
         }
     }
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    float tot = 0.0f;
+    auto block_sum = [&](float x, int k) {
+        x = wave_sum(x);
+        if ((tid & 63) == 0) red[k][tid >> 6] = x;
+        __syncthreads();
+        float tot = 0.0f;
+        for (int w = 0; w < nw; ++w) tot += red[k][w];
+        return tot;
+    };
+    const float t1 = block_sum(s1, 0);
+    if (nb) {
+        const float mu = t1 / (float)p.N;
+        float s2 = 0.0f;
+        if (live) {
 #pragma unroll
-    for (int w = 0; w < 16; ++w) tot += red[w];
-    const float sc = rsqrtf(tot / (float)p.N + p.norm_eps);
-    if (live) {
+            for (int e = 0; e < 4; ++e) s2 += (v[e] - mu) * (v[e] - mu);
+        }
+        const float sc = rsqrtf(block_sum(s2, 1) / (float)p.N + p.norm_eps);
+        if (live) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Y[(size_t)m * p.N + n0 + e] = from_f32<T>(to_f32(g[n0 + e]) * (v[e] * sc));
+            for (int e = 0; e < 4; ++e) Y[(size_t)m * p.N + n0 + e] = from_f32<T>((v[e] - mu) * sc * to_f32(g[n0 + e]) + to_f32(nb[n0 + e]));
+        }
+    } else {
+        const float sc = rsqrtf(t1 / (float)p.N + p.norm_eps);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Y[(size_t)m * p.N + n0 + e] = from_f32<T>(to_f32(g[n0 + e]) * (v[e] * sc));
+        }
     }
 }
 
@@ -556,7 +577,7 @@ template <typename T, int EPI> bool launch_split(hipStream_t s, GemmArgs a, int 
     a.nsplit = S;
     launch_cfg<T, EPI, Cfg256, true>(s, a, S);
     if (EPI == EPI_NONE && a.norm_out && a.norm_w && a.tile_base == 0 && a.N <= 4096 && a.N % 4 == 0) {
-        hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(((a.N / 4 + 63) / 64) * 64), 0, s, a);
         return true;
     }
     const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;

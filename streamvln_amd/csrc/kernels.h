@@ -27,6 +27,7 @@ struct GemmArgs {
     // when the product takes the split-K path with N <= 4096 the slab reduce also writes norm_out = rmsnorm(C) * norm_w and
     // launch_gemm returns true; otherwise norm_out is untouched (false) and the caller runs launch_rmsnorm itself
     const void* norm_w; void* norm_out; float norm_eps;
+    const void* norm_b;           // non-null: LayerNorm (mean/variance, weight norm_w, bias norm_b) instead of RMSNorm -- the ViT's ln1 / ln2
     int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced

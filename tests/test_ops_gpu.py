@@ -64,33 +64,43 @@ def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,split,expect_fused", [
-    (212, 512, 1024, 0, True),      # steady prefill rows: heuristic K split -> fused reduce + norm
-    (37, 3584, 3584, 4, True),      # o_proj at true width, ragged M
-    (212, 3584, 18944 // 8, 3, True),   # down_proj-like
-    (1, 512, 512, 2, True),
-    (700, 2048, 1024, 0, False),    # many 128x128 tiles -> unsplit: the caller must run the norm itself
+@pytest.mark.parametrize("M,N,K,split,kind,expect_fused", [
+    (212, 512, 1024, 0, "rms", True),       # steady prefill rows: heuristic K split -> fused reduce + norm
+    (37, 3584, 3584, 4, "rms", True),       # o_proj at true width, ragged M
+    (212, 3584, 18944 // 8, 3, "rms", True),    # down_proj-like
+    (1, 512, 512, 2, "rms", True),
+    (700, 2048, 1024, 0, "rms", False),     # many 128x128 tiles -> unsplit: the caller must run the norm itself
+    (729, 1152, 1152, 0, "ln", True),       # SigLIP out_proj -> layer_norm2, one frame
+    (729, 1152, 4304, 0, "ln", True),       # SigLIP fc2 -> next layer_norm1
+    (50, 144, 288, 2, "ln", True),
 ])
-def test_gemm_fused_rmsnorm(dtype, M, N, K, split, expect_fused):
-    """o_proj / down_proj + residual with the following RMSNorm emitted by the split-K reduce (modeling_qwen2.py:269-299)."""
+def test_gemm_fused_norm(dtype, M, N, K, split, kind, expect_fused):
+    """o_proj / down_proj (+ residual) with the following RMSNorm, and SigLIP out_proj / fc2 (+ bias + residual) with the following
+    LayerNorm, emitted by the split-K reduce (modeling_qwen2.py:269-299, siglip_encoder.py:269-305)."""
     import ctypes as C
     m = engine(TINY, dtype)
+    ln = kind == "ln"
     A, Wt = q(rnd((M, K), 11), dtype), q(rnd((N, K), 12, 1.0 / math.sqrt(K)), dtype)
     r, g = q(rnd((M, N), 13), dtype), q(1.0 + rnd((N,), 14, 0.2), dtype)
-    h = q(A @ Wt.t() + r, dtype)                       # the residual stream is stored in the engine dtype, the norm reads it back
-    exp_norm = O.rms_norm(h, g, 1e-6)
+    b = q(rnd((N,), 15, 0.1), dtype) if ln else None
+    nb = q(rnd((N,), 16, 0.1), dtype) if ln else None
+    full = A @ Wt.t() + r + (b if ln else 0.0)
+    norm = (lambda t: O.layer_norm(t, g, nb, 1e-6)) if ln else (lambda t: O.rms_norm(t, g, 1e-6))
     dA, dW, dg = A.to(dtype).cuda(), Wt.to(dtype).cuda(), g.to(dtype).cuda()
+    db = b.to(dtype).cuda() if ln else None
+    dnb = nb.to(dtype).cuda() if ln else None
     x = r.to(dtype).cuda()                             # in place: C == res, like the engine's residual stream
     xn = torch.full((M, N), 7.0, dtype=dtype, device="cuda")
     fused = C.c_int32(-1)
     torch.cuda.synchronize()
-    chk(m._lib.svln_op_gemm_rmsnorm(m._h, ptr(dA), K, ptr(dW), K, ptr(x), N, ptr(x), N, ptr(dg), ptr(xn), 1e-6, M, N, K, split, C.byref(fused)))
+    chk(m._lib.svln_op_gemm_norm(m._h, ptr(dA), K, ptr(dW), K, ptr(x), N, ptr(db), ptr(x), N, ptr(dg), ptr(dnb), ptr(xn), 1e-6, M, N, K, split,
+                                 C.byref(fused)))
     assert fused.value == int(expect_fused)
-    assert_close(x, A @ Wt.t() + r, dtype, f"gemm+res {M}x{N}x{K}")
+    assert_close(x, full, dtype, f"gemm+res {M}x{N}x{K}")
     if expect_fused:
-        if dtype == torch.bfloat16:                    # compare against the norm of the rows the kernel actually stored
-            exp_norm = O.rms_norm(x.float().cpu(), g, 1e-6)
-        assert_close(xn, exp_norm, dtype, f"fused rmsnorm {M}x{N}x{K}")
+        # the residual stream is stored in the engine dtype and the norm reads the stored rows
+        exp_norm = norm(x.float().cpu()) if dtype == torch.bfloat16 else norm(full)
+        assert_close(xn, exp_norm, dtype, f"fused {kind} norm {M}x{N}x{K}")
     else:
         assert float(xn.float().min()) == 7.0 and float(xn.float().max()) == 7.0
 
