@@ -129,26 +129,43 @@ __global__ __launch_bounds__(256) void frame_hash_kernel(const uint32_t* pix, si
     atomicAdd(out + 2 * f + 1, b);
 }
 
-// ViT K/V packing: qkv [F*S][3*Hv] -> K pages [tile][F*heads][64][HDP] (zero padded), Vt [tile][F*heads][VROWS][64]
+// ViT K/V packing: qkv [F*S][3*Hv] -> K pages [tile][F*heads][64][HDP] (zero padded), Vt [tile][F*heads][VROWS][64].
+// One workgroup per (64-key tile, frame*head).  K rows are copied as 16-byte chunks; V goes through an LDS tile
+// [64 keys][HD] (16-byte chunk loads, row pitch padded by one chunk against bank conflicts) and leaves transposed as
+// 16-byte chunks of 8 (4 for fp32) consecutive keys per head dim.  Requires HD % chunk == 0 and ld % chunk == 0.
 template <typename T>
 __global__ __launch_bounds__(256) void vit_kv_pack_kernel(const T* qkv, int ld, T* Kpool, T* Vpool, int F, int S, int heads, int HD,
                                                           int HDP, int VROWS) {
+    extern __shared__ __attribute__((aligned(16))) char pack_smem[];
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    T* vt = (T*)pack_smem;
     const int tile = blockIdx.x, kh = blockIdx.y;          // kh = f*heads + head
     const int f = kh / heads, head = kh % heads, Hv = heads * HD;
     const int nkv = F * heads;
+    const int hc = HD / EPC, hpc = HDP / EPC, pitch = HD + EPC;
     T* kp = Kpool + ((size_t)tile * nkv + kh) * 64 * HDP;
     T* vp = Vpool + ((size_t)tile * nkv + kh) * VROWS * 64;
-    for (int e = threadIdx.x; e < 64 * HDP; e += 256) {
-        const int key = e / HDP, d = e % HDP, s = tile * 64 + key;
-        T v = from_f32<T>(0.0f);
-        if (s < S && d < HD) v = qkv[(size_t)(f * S + s) * ld + Hv + head * HD + d];
-        kp[e] = v;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    for (int e = threadIdx.x; e < 64 * hpc; e += 256) {
+        const int key = e / hpc, cchunk = e % hpc, s = tile * 64 + key;
+        uint4 v = zero;
+        if (s < S && cchunk < hc) v = *(const uint4*)(qkv + (size_t)(f * S + s) * ld + Hv + head * HD + cchunk * EPC);
+        *(uint4*)(kp + (size_t)key * HDP + cchunk * EPC) = v;
     }
-    for (int e = threadIdx.x; e < VROWS * 64; e += 256) {
-        const int d = e / 64, key = e % 64, s = tile * 64 + key;
-        T v = from_f32<T>(0.0f);
-        if (s < S && d < HD) v = qkv[(size_t)(f * S + s) * ld + 2 * Hv + head * HD + d];
-        vp[e] = v;
+    for (int e = threadIdx.x; e < 64 * hc; e += 256) {
+        const int key = e / hc, cchunk = e % hc, s = tile * 64 + key;
+        uint4 v = zero;
+        if (s < S) v = *(const uint4*)(qkv + (size_t)(f * S + s) * ld + 2 * Hv + head * HD + cchunk * EPC);
+        *(uint4*)(vt + key * pitch + cchunk * EPC) = v;
+    }
+    __syncthreads();
+    constexpr int KC = 64 / EPC;                          // key chunks per Vt row
+    for (int e = threadIdx.x; e < VROWS * KC; e += 256) {
+        const int d = e / KC, kc = e % KC;
+        T out[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) out[j] = d < HD ? vt[(kc * EPC + j) * pitch + d] : from_f32<T>(0.0f);
+        *(uint4*)(vp + (size_t)d * 64 + kc * EPC) = *(const uint4*)out;
     }
 }
 
@@ -267,7 +284,8 @@ template <typename T> void launch_vit_kv_pack(hipStream_t s, const void* qkv, in
     constexpr int EPC = Elt<T>::PER_CHUNK;
     const int hdc = (((head_dim + EPC - 1) / EPC) + 1) & ~1;
     const int vrows = ((head_dim + 31) / 32) * 32;
-    hipLaunchKernelGGL((vit_kv_pack_kernel<T>), dim3((S + 63) / 64, F * heads), dim3(256), 0, s, (const T*)qkv, ld, (T*)Kpool, (T*)Vpool, F, S,
+    const size_t lds = (size_t)64 * (head_dim + EPC) * sizeof(T);
+    hipLaunchKernelGGL((vit_kv_pack_kernel<T>), dim3((S + 63) / 64, F * heads), dim3(256), lds, s, (const T*)qkv, ld, (T*)Kpool, (T*)Vpool, F, S,
                        heads, head_dim, hdc * EPC, vrows);
 }
 template <typename T> void launch_patchify(hipStream_t s, const float* pix, void* out, int F, int image, int patch, int kp) {
