@@ -295,14 +295,14 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
     if (!valid) return;
 
     if (p.nsplit > 1) {
-        // partial: [split][kh][rho][HD + 2] = O (unnormalised), m, l
-        float* dst = p.part + (((size_t)blockIdx.z * p.n_kv_total + kh) * p.rows_pad + rho) * (HD + 2);
+        // partial: [split][kh][rho][HD + 4] = O (unnormalised), m, l, pad; 16-byte stores of 4 consecutive channels
+        float* dst = p.part + (((size_t)blockIdx.z * p.n_kv_total + kh) * p.rows_pad + rho) * (HD + ATTN_PART_PAD);
 #pragma unroll
         for (int d = 0; d < G::DT; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dd = d * 32 + acc_row(e, lane);
-                if (dd < HD) dst[dd] = O[d][e];
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int dd = d * 32 + acc_row(e4 * 4, lane);
+                if (dd < HD) *(float4*)(dst + dd) = make_float4(O[d][4 * e4], O[d][4 * e4 + 1], O[d][4 * e4 + 2], O[d][4 * e4 + 3]);
             }
         if (h == 0) { dst[HD] = m; dst[HD + 1] = l; }
         return;
@@ -500,9 +500,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     }
     l += __shfl_xor(l, 32, 64);
     if (!valid) return;
-    float* dst = p.part + (size_t)env * p.part_bstride + (((size_t)z * p.n_kv_total + kh) * p.rows_pad + r) * 130;
+    float* dst = p.part + (size_t)env * p.part_bstride + (((size_t)z * p.n_kv_total + kh) * p.rows_pad + r) * (128 + ATTN_PART_PAD);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dst[wave * 32 + acc_row(e, lane)] = O[e];
+    for (int e4 = 0; e4 < 4; ++e4)
+        *(float4*)(dst + wave * 32 + acc_row(e4 * 4, lane)) = make_float4(O[4 * e4], O[4 * e4 + 1], O[4 * e4 + 2], O[4 * e4 + 3]);
     if (wave == 0 && h == 0) { dst[128] = m; dst[129] = l; }
 }
 
@@ -515,8 +516,8 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
     const int kv_len = p.slots ? p.slots[env].pos + 1 : (p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len);
     const int tiles = (kv_len + 63) >> 6;
     const int nsplit = min(min(p.nsplit, 64), (tiles + p.tiles_per_split - 1) / p.tiles_per_split);
-    const size_t split_stride = (size_t)p.n_kv_total * p.rows_pad * (HD + 2);
-    const float* base = p.part + (size_t)env * p.part_bstride + ((size_t)kh * p.rows_pad + rho) * (HD + 2);
+    const size_t split_stride = (size_t)p.n_kv_total * p.rows_pad * (HD + ATTN_PART_PAD);
+    const float* base = p.part + (size_t)env * p.part_bstride + ((size_t)kh * p.rows_pad + rho) * (HD + ATTN_PART_PAD);
     float mz = -INFINITY, lz = 0.0f;
     if (lane < nsplit) { mz = base[lane * split_stride + HD]; lz = base[lane * split_stride + HD + 1]; }
     const float mstar = wave_max(mz);

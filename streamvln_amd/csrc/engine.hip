@@ -267,8 +267,9 @@ public:
         tiles_per_split = 1;                       // decode: one 64-key page per workgroup, <= 64 splits
         while ((pages_per_env + tiles_per_split - 1) / tiles_per_split > 64) ++tiles_per_split;
         nsplit_max = (pages_per_env + tiles_per_split - 1) / tiles_per_split;
-        {   // partials: decode [nsplit_max][nkv][32][130], prefill split-KV [<= 8][nkv][PREFILL_SPLIT_ROWS][130]
-            const size_t dec = (size_t)MAXB * nsplit_max * nkv * 32 * 130, pre = (size_t)8 * nkv * PREFILL_SPLIT_ROWS * 130;
+        {   // partials: decode [nsplit_max][nkv][32][132], prefill split-KV [<= 8][nkv][PREFILL_SPLIT_ROWS][132]
+            constexpr int PW = 128 + ATTN_PART_PAD;
+            const size_t dec = (size_t)MAXB * nsplit_max * nkv * 32 * PW, pre = (size_t)8 * nkv * PREFILL_SPLIT_ROWS * PW;
             attn_part_elems = dec > pre ? dec : pre;
             attn_part = dalloc<float>(attn_part_elems);
         }
@@ -394,7 +395,7 @@ public:
         // one frame = 6 row blocks x 16 heads = 96 workgroups: split the 12 key tiles 3 ways to fill the chip
         const int wgs = ((S + 127) / 128) * F * vheads, rows_pad = ((S + 127) / 128) * 128;
         // (measured: 6 splits are slower than 3 -- the fp32 partials double -- and unsplit is 35 us against 18 + 8 for split + combine)
-        if (wgs < 192 && vtiles >= 6 && (size_t)3 * F * vheads * rows_pad * (vhd + 2) <= attn_part_elems) {
+        if (wgs < 192 && vtiles >= 6 && (size_t)3 * F * vheads * rows_pad * (vhd + ATTN_PART_PAD) <= attn_part_elems) {
             a.nsplit = 3; a.tiles_per_split = (vtiles + 2) / 3; a.rows_pad = rows_pad;
         }
         return a;
@@ -719,7 +720,7 @@ public:
             launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
             AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, qd, 1, 0, 0, true);
             a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr;
-            a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * 130;
+            a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * (128 + ATTN_PART_PAD);
             launch_attention<T>(st, a, 128, 1);
             launch_attention_combine<T>(st, a, 128);
             launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));

@@ -76,6 +76,7 @@ void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_i
 // one environment of a batched decode step
 struct DecodeSlot { const int* page_table; int pos; int pad; };
 
+constexpr int ATTN_PART_PAD = 4;    // floats after the HD partial outputs of a row: m, l, 2 unused
 struct AttnArgs {
     const void* Q; int q_stride;
     void* O; int o_stride;
@@ -88,7 +89,7 @@ struct AttnArgs {
     float scale;
     int causal;
     int nsplit, tiles_per_split;  // split-KV: gridDim.z = nsplit, partials in `part`
-    float* part;                  // [nsplit][n_kv_total][rows_pad][HD + 2] fp32 (O unnormalised, m, l)
+    float* part;                  // [nsplit][n_kv_total][rows_pad][HD + ATTN_PART_PAD] fp32 (O unnormalised, m, l, 2 pad: rows stay 16-byte aligned)
     int rows_pad;
     // decode fusion (T == 1, head_dim 128, one wave per workgroup): Q points at the UN-roped qkv row
     // [(nq + 2 nkv) * 128]; the kernel applies RoPE to q in registers, and the workgroup that owns the page of
