@@ -37,12 +37,13 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_> 
     static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     static constexpr int A_LOADS = BM * CH / THREADS, W_LOADS = BN * CH / THREADS;
     static constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;   // 32x32 accumulator tiles per wave
-    static_assert(BM / WM % 32 == 0 && BN / WN == 64, "wave tile: rows a multiple of 32, 64 columns ([gate 32 | up 32] for SwiGLU)");
+    static_assert(BM / WM % 32 == 0 && BN / WN % 64 == 0, "wave tile: rows a multiple of 32, columns a multiple of 64 ([gate 32 | up 32] blocks for SwiGLU)");
     static_assert(BM * CH % THREADS == 0 && BN * CH % THREADS == 0, "staging must divide evenly");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
-using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2>;       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
+using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2>;
+using CfgBig4 = TileCfg<256, 256, 2, 2, 128, false, 2>;      // 4 waves, wave tile 128x128 (4x4 accumulators in AGPRs): half the LDS fragment reads per MFMA       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
 
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     };
 
     constexpr int MI = C::MI, NJ = C::NJ, STEPS = C::CH / 2, RD = MI + NJ;     // fragment reads per macro step
-    constexpr int WROWS = C::BM / C::WM;
+    constexpr int WROWS = C::BM / C::WM, WCOLS = C::BN / C::WN;
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int rw_ = wc * 64 + j * 32 + r32;
+            const int rw_ = wc * WCOLS + j * 32 + r32;
             offW[s][j] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
         }
     }
@@ -346,7 +347,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
     };
     auto wait_step = [&](int k, bool more) {          // step in buffer k landed (`more`: the next step's RD reads stay in flight)
-        if constexpr (MI == 4) {
+        if constexpr (MI == 4 && NJ == 4) {
+            if (more) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]), "+v"(fb[k][2]), "+v"(fb[k][3]) : "n"(RD));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]), "+v"(fb[k][2]), "+v"(fb[k][3]));
+        } else if constexpr (MI == 4) {
             if (more) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]) : "n"(RD));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]));
         } else {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int nn = col0 + wc * 64 + j * 32 + r32;
+                const int nn = col0 + wc * WCOLS + j * 32 + r32;
                 if (nn >= p.N) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -406,22 +410,25 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     const T* bias = (const T*)p.bias;
     const T* res = (const T*)p.res;
     if (EPI == EPI_SWIGLU) {
-        const int n_out = ((col0 + wc * 64) >> 1) + r32;
-        const bool ok_n = (col0 + wc * 64 + 32 + r32) < p.N;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int jp = 0; jp < NJ / 2; ++jp) {                 // one [gate 32 | up 32] block per accumulator pair
+            const int n_out = ((col0 + wc * WCOLS + jp * 64) >> 1) + r32;
+            const bool ok_n = (col0 + wc * WCOLS + jp * 64 + 32 + r32) < p.N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
-                if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][0][r]) * acc[i][1][r]);
-            }
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
+                    if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][2 * jp][r]) * acc[i][2 * jp + 1][r]);
+                }
+        }
         return;
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int nn = col0 + wc * 64 + j * 32 + r32;
+            const int nn = col0 + wc * WCOLS + j * 32 + r32;
             if (nn >= p.N) continue;
             const float bv = bias ? to_f32(bias[nn]) : 0.0f;
 #pragma unroll
@@ -607,6 +614,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CfgBig, false>), dim3(tilesbig), dim3(CfgBig::THREADS), CfgBig::NBUF * CfgBig::STAGE_BYTES, s, a);
         return false;
     }
+
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     const bool want128 = a.M > 256 && tiles128 >= 96;
     if ((want128 && a.force_split == 0) || (a.force_cfg & 0xFFF) == 128) {
