@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-feature-cache-pass", action="store_true")
     ap.add_argument("--no-batched-pass", action="store_true")
+    ap.add_argument("--no-fp8-pass", action="store_true")
     ap.add_argument("--batched-envs", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
@@ -227,6 +228,35 @@ def main():
                   "hits": hits, "misses": misses,
                   "note": "opt-in: pooled features of frames already encoded in the episode are reused (content hash) instead of "
                           "re-running the ViT on the 8 <memory> frames; not the headline value"}
+    # opt-in fp8 (e4m3) decode weights (no reference counterpart): same stream, decode steps + lm_head read the fp8 copies.
+    # Reduced precision -> reported separately, never the headline value.
+    fp8 = None
+    if not a.no_fp8_pass and a.dtype == "bf16":
+        model.set_feature_cache(0)
+        run.cache_frames = 0
+        model.set_fp8_decode(True)
+        while run.step <= EP_STEPS - NUM_FUTURE:
+            run.turn()
+        for _ in range(a.warmup):
+            run.turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0f = time.perf_counter()
+        for _ in range(a.steps):
+            run.turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtf = time.perf_counter() - t0f
+        if world > 1:
+            tt = torch.tensor([dtf], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtf = float(tt.item())
+        model.set_fp8_decode(False)
+        fp8 = {"value": round(NUM_FUTURE * a.steps * world / dtf, 2), "ms_per_step": round(dtf / a.steps * 1e3, 3), "dtype": "bf16 activations, e4m3 decode weights",
+               "note": "opt-in: decode-step GEMVs and lm_head stream per-row-scaled e4m3 copies of the LLM weights (half the HBM bytes per "
+                       "token); prefill and vision stay bf16; reduced precision, not the headline value"}
     # third pass: BASELINE configs[4]-style concurrent envs on this GPU, stepped in lockstep through generate_batch
     # (build-side extension; the headline `value` is the 1-env-per-GPU stream of configs[1]).
     batched = None
@@ -292,6 +322,7 @@ def main():
             "metric_allreduce_check": summary,
             "roofline": roof,
             "with_feature_cache": cached,
+            "fp8_decode_weights": fp8,
             "batched_envs": batched,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -89,6 +89,10 @@ int svln_get_top2(svln_engine* h, float* host_out2);
 
 /* -- decode execution mode + timing probes (bench.py) */
 int svln_set_decode_graph(svln_engine* h, int enable);     /* replay the per-token decode step as a hipGraph */
+/* Opt-in, no reference counterpart: the single-env decode step and the lm_head stream OCP e4m3 copies of the LLM
+ * weights (one fp32 scale per output row, quantised on the device from the loaded tensors at the first enable) instead of the bf16
+ * ones -- half the HBM bytes per generated token.  bf16 engines only; prefill, vision and svln_generate_batch keep bf16 weights. */
+int svln_set_fp8_decode(svln_engine* h, int enable);
 int svln_probe_reset(svln_engine* h);
 int svln_probe_read(svln_engine* h, double* total_ms, int64_t* launches, double* bytes_per_launch);
 int svln_phase_times(svln_engine* h, double* vision_ms, double* prefill_ms, double* decode_ms, int reset);
@@ -113,6 +117,11 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
+/* fp8 weight-only pieces of svln_set_fp8_decode: per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 16 == 0,
+ * scale[r] = max|W[r]| / 448, round to nearest even), and the GEMV over such a matrix (same epilogues as svln_op_gemv) */
+int svln_op_quant_fp8(svln_engine* h, const void* w_bf16, int64_t rows, int cols, void* w8, float* scale);
+int svln_op_gemv_fp8(svln_engine* h, const void* w8, const float* scale, int ldw, const void* x, const void* norm_w, float eps, const void* bias,
+                     const void* res, void* y, int N, int K, int epi, int32_t* host_token);
 int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps);
 int svln_op_layernorm(svln_engine* h, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps);
 /* attention over caller-provided q [T][q_stride] and k/v [S][kv_stride] (engine packs them into pages):

@@ -53,6 +53,7 @@ SIGNATURES = {
     "svln_get_frame_feats": (_I, [_P, _I, _I, _PF]),
     "svln_get_top2": (_I, [_P, _PF]),
     "svln_set_decode_graph": (_I, [_P, _I]),
+    "svln_set_fp8_decode": (_I, [_P, _I]),
     "svln_probe_reset": (_I, [_P]),
     "svln_probe_read": (_I, [_P, _PD, _PI64, _PD]),
     "svln_phase_times": (_I, [_P, _PD, _PD, _PD, _I]),
@@ -61,6 +62,8 @@ SIGNATURES = {
     "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemm_norm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _PI32]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
+    "svln_op_quant_fp8": (_I, [_P, _P, _I64, _I, _P, _P]),
+    "svln_op_gemv_fp8": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
     "svln_op_rmsnorm": (_I, [_P, _P, _P, _P, _I, _I, _F]),
     "svln_op_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
     "svln_op_attention_llm": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _I]),

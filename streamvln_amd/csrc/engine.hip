@@ -64,6 +64,7 @@ struct EngineBase {
     virtual void get_top2(float* out) = 0;
     virtual void sync() = 0;
     virtual void set_graph(int enable) = 0;
+    virtual void set_fp8_decode(int enable) = 0;
     virtual void probe_reset() = 0;
     virtual void probe_read(double* ms, int64_t* launches, double* bytes) = 0;
     virtual void phase_times(double* v, double* p, double* d, int reset) = 0;
@@ -71,6 +72,7 @@ struct EngineBase {
     virtual void feature_cache_stats(int64_t* hits, int64_t* misses) = 0;
     virtual bool op_gemm(const GemmArgs& a) = 0;
     virtual void op_gemv(GemvArgs a, int32_t* host_token) = 0;
+    virtual void op_quant_fp8(const void* w, int64_t rows, int cols, void* w8, float* scale) = 0;
     virtual void op_rmsnorm(const void* x, const void* g, void* y, int rows, int n, float eps) = 0;
     virtual void op_layernorm(const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) = 0;
     virtual void op_attention_llm(void* qkv, int ld, int T, int P, const void* ctx, int ctx_T, void* out, int o_stride, int nsplit) = 0;
@@ -94,7 +96,9 @@ public:
     int pages_per_env, pages_total;
 
     struct VLayer { T *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
-    struct LLayer { T *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gu_w, *down_w, *kpool, *vpool; };
+    struct Q8 { uint8_t* q = nullptr; float* s = nullptr; };      // fp8 (e4m3) copy of a weight matrix + per-row scales (opt-in decode mode)
+    struct LLayer { T *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gu_w, *down_w, *kpool, *vpool; Q8 qkv8, o8, gu8, down8; };
+    Q8 lm_head8; bool fp8_on = false, fp8_built = false;
     T *patch_w, *patch_b, *pos_emb, *proj0_w, *proj0_b, *proj2_w, *proj2_b, *embed, *final_norm, *lm_head;
     std::vector<VLayer> vl;
     std::vector<LLayer> ll;
@@ -605,13 +609,14 @@ public:
     GemvArgs gemv_args(const void* W, int ldw, const void* xin, const void* norm_w, const void* bias, const void* res, void* y, int N, int K,
                        int epi) {
         GemvArgs a; a.W = W; a.ldw = ldw; a.x = xin; a.norm_w = norm_w; a.eps = c.rms_eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K;
-        a.epi = epi; a.part_val = part_val; a.part_idx = part_idx; return a;
+        a.epi = epi; a.part_val = part_val; a.part_idx = part_idx; a.w8 = nullptr; a.scale = nullptr; return a;
     }
+    GemvArgs with8(GemvArgs a, const Q8& q) { if (fp8_on) { a.w8 = q.q; a.scale = q.s; } return a; }
     // final norm -> hidden tap row -> lm_head arg-max -> d_token  (lm_head on the LAST position only)
     void head(const T* xrow, int tap_row) {
         T* tap = hid_tap + (size_t)(tap_row < HID_TAP_ROWS ? tap_row : HID_TAP_ROWS - 1) * H;
         launch_rmsnorm<T>(st, xrow, final_norm, tap, 1, H, c.rms_eps);
-        launch_gemv<T>(st, gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX));
+        launch_gemv<T>(st, with8(gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX), lm_head8));
         launch_argmax_final(st, part_val, part_idx, gemv_grid(V), d_token, d_top2);
     }
     // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_dyn,
@@ -627,13 +632,13 @@ public:
         if (on()) launch_gather_rows<T>(st, d_token, embed, feats, x, 1, H);
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
-            if (on()) launch_gemv<T>(st, gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE));
+            if (on()) launch_gemv<T>(st, with8(gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE), L.qkv8));
             AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, 1, 0, 0, true);
             if (on()) launch_attention<T>(st, a, 128, 1);
             if (on()) launch_attention_combine<T>(st, a, 128);
-            if (on()) launch_gemv<T>(st, gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE));
-            if (on()) launch_gemv<T>(st, gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU));
-            if (on()) launch_gemv<T>(st, gemv_args(L.down_w, I, hbuf, nullptr, nullptr, x, x, H, I, EPI_NONE));
+            if (on()) launch_gemv<T>(st, with8(gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE), L.o8));
+            if (on()) launch_gemv<T>(st, with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8));
+            if (on()) launch_gemv<T>(st, with8(gemv_args(L.down_w, I, hbuf, nullptr, nullptr, x, x, H, I, EPI_NONE), L.down8));
         }
     }
 
@@ -646,7 +651,7 @@ public:
     // layer-0 gate/up SwiGLU GEMV with the kernel's own begin/end timestamps
     void probe_launch(Env&) {
         const LLayer& L = ll[0];
-        launch_gemv_timed<T>(st, gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), probe_ev[probe_used],
+        launch_gemv_timed<T>(st, with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8), probe_ev[probe_used],
                              probe_ev[probe_used + 1]);
         probe_used += 2;
     }
@@ -910,6 +915,33 @@ public:
     void get_top2(float* out) override { out[0] = h_top2[0]; out[1] = h_top2[1]; }
     void sync() override { HIP_CHECK(hipStreamSynchronize(st)); }
     void set_graph(int enable) override { use_graph = enable != 0; if (!use_graph) drop_graphs(); }
+    // Opt-in (no reference counterpart): the single-env decode step and the lm_head read e4m3 copies of the LLM
+    // weights (per-row scale) instead of the bf16 ones; prefill, vision and the lockstep multi-env path keep bf16.  Both copies stay
+    // resident (15.2 + 7.6 GB of 288).  Quantised from the tensors loaded at the time of the first enable.
+    void set_fp8_decode(int enable) override {
+        if (!enable) { if (fp8_on) drop_graphs(); fp8_on = false; return; }
+        REQUIRE(sizeof(T) == 2, "fp8 decode weights need the bf16 engine");
+        REQUIRE(weights_missing() == 0, g_err);
+        REQUIRE(H % 16 == 0 && I % 16 == 0, "fp8 decode weights need hidden and intermediate sizes that are multiples of 16");
+        if (!fp8_built) {
+            auto build = [&](Q8& q, const T* w, int64_t rows, int cols) {
+                q.q = dalloc<uint8_t>((size_t)rows * cols);
+                q.s = dalloc<float>((size_t)rows);
+                launch_quant_fp8_rows(st, w, cols, q.q, q.s, rows, cols);
+            };
+            for (auto& L : ll) {
+                build(L.qkv8, L.qkv_w, qkv_dim, H);
+                build(L.o8, L.o_w, H, nq * 128);
+                build(L.gu8, L.gu_w, 2 * I, H);
+                build(L.down8, L.down_w, H, I);
+            }
+            build(lm_head8, lm_head, V, H);
+            HIP_CHECK(hipStreamSynchronize(st));
+            fp8_built = true;
+        }
+        if (!fp8_on) drop_graphs();
+        fp8_on = true;
+    }
     void probe_reset() override {
         if (probe_ev.empty()) { probe_ev.resize(4096); for (auto& ev : probe_ev) HIP_CHECK(hipEventCreate(&ev)); }
         probe_used = 0; probe_on = true;
@@ -937,6 +969,7 @@ public:
         return fused;
     }
     void op_gemv(GemvArgs a, int32_t* host_token) override {
+        REQUIRE(a.w8 == nullptr || sizeof(T) == 2, "fp8 weights need the bf16 engine");
         a.part_val = part_val; a.part_idx = part_idx;
         launch_gemv<T>(st, a);
         if (a.epi == EPI_ARGMAX) {
@@ -944,6 +977,12 @@ public:
             const int t = read_token();
             if (host_token) *host_token = t;
         }
+        sync();
+    }
+    void op_quant_fp8(const void* w, int64_t rows, int cols, void* w8, float* scale) override {
+        REQUIRE(sizeof(T) == 2, "fp8 quantisation reads bf16 weights");
+        REQUIRE(cols % 16 == 0, "cols must be a multiple of 16");
+        launch_quant_fp8_rows(st, w, cols, w8, scale, rows, cols);
         sync();
     }
     void op_rmsnorm(const void* xi, const void* g, void* y, int rows, int n, float eps) override { launch_rmsnorm<T>(st, xi, g, y, rows, n, eps); sync(); }
@@ -1045,6 +1084,7 @@ int svln_get_embeds(svln_engine* h, int env, int start, int n, float* out) { API
 int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEGIN h->impl->get_feats(start, n, out); API_END }
 int svln_get_top2(svln_engine* h, float* out) { API_BEGIN h->impl->get_top2(out); API_END }
 int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN h->impl->set_graph(enable); API_END }
+int svln_set_fp8_decode(svln_engine* h, int enable) { API_BEGIN h->impl->set_fp8_decode(enable); API_END }
 int svln_probe_reset(svln_engine* h) { API_BEGIN h->impl->probe_reset(); API_END }
 int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN h->impl->probe_read(ms, launches, bytes); API_END }
 int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN h->impl->phase_times(v, p, d, reset); API_END }
@@ -1074,7 +1114,19 @@ int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const vo
                  int N, int K, int epi, int32_t* host_token) {
     API_BEGIN
     GemvArgs a; a.W = W; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
-    a.part_val = nullptr; a.part_idx = nullptr;
+    a.part_val = nullptr; a.part_idx = nullptr; a.w8 = nullptr; a.scale = nullptr;
+    h->impl->op_gemv(a, host_token);
+    API_END
+}
+int svln_op_quant_fp8(svln_engine* h, const void* w_bf16, int64_t rows, int cols, void* w8, float* scale) {
+    API_BEGIN h->impl->op_quant_fp8(w_bf16, rows, cols, w8, scale); API_END
+}
+int svln_op_gemv_fp8(svln_engine* h, const void* w8, const float* scale, int ldw, const void* x, const void* norm_w, float eps, const void* bias,
+                     const void* res, void* y, int N, int K, int epi, int32_t* host_token) {
+    API_BEGIN
+    if (K % 16 != 0) throw std::runtime_error("K must be a multiple of 16");
+    GemvArgs a; a.W = nullptr; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
+    a.part_val = nullptr; a.part_idx = nullptr; a.w8 = w8; a.scale = scale;
     h->impl->op_gemv(a, host_token);
     API_END
 }

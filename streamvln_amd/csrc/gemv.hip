@@ -26,31 +26,17 @@ constexpr int GEMV_WAVES = GEMV_THREADS / 64;
 
 // x in LDS, split in 16-byte planes so that consecutive lanes read consecutive 16 B (conflict-free):
 // floats of chunk ci, part p (4 floats each) live at xs[p * nch * 4 + ci * 4 ...].
+// With a fused RMSNorm the LDS copy holds g * x (one pass over x, one barrier) and the function returns rsqrt(mean(x^2) + eps):
+// y = rstd * (W . (g * x)) -- the scale is applied once per output in the epilogue (same folding as gemv_ksplit_kernel).
 template <typename T>
-SVLN_DEV void stage_x(float* xs, const GemvArgs& p, int nch) {
+SVLN_DEV float stage_x(float* xs, const GemvArgs& p, int nch) {
     constexpr int EPC = Elt<T>::PER_CHUNK;
     constexpr int PARTS = EPC / 4;
+    __shared__ float red[GEMV_WAVES];
     const T* x = (const T*)p.x;
-    const int tid = threadIdx.x;
-    float scale = 1.0f;
-    if (p.norm_w) {
-        __shared__ float red[GEMV_WAVES];
-        float ss = 0.0f;
-        for (int ci = tid; ci < nch; ci += GEMV_THREADS) {
-            float f[EPC];
-            chunk_to_f32<T>(*(const uint4*)(x + (size_t)ci * EPC), f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) ss += f[e] * f[e];
-        }
-        ss = wave_sum(ss);
-        if ((tid & 63) == 0) red[tid >> 6] = ss;
-        __syncthreads();
-        float tot = 0.0f;
-#pragma unroll
-        for (int w = 0; w < GEMV_WAVES; ++w) tot += red[w];
-        scale = rsqrtf(tot / (float)p.K + p.eps);
-    }
     const T* g = (const T*)p.norm_w;
+    const int tid = threadIdx.x;
+    float ss = 0.0f;
     for (int ci = tid; ci < nch; ci += GEMV_THREADS) {
         float f[EPC];
         chunk_to_f32<T>(*(const uint4*)(x + (size_t)ci * EPC), f);
@@ -58,13 +44,22 @@ SVLN_DEV void stage_x(float* xs, const GemvArgs& p, int nch) {
             float gf[EPC];
             chunk_to_f32<T>(*(const uint4*)(g + (size_t)ci * EPC), gf);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = gf[e] * (f[e] * scale);       // Qwen2RMSNorm: weight * (x * rsqrt)
+            for (int e = 0; e < EPC; ++e) { ss = fmaf(f[e], f[e], ss); f[e] *= gf[e]; }
         }
 #pragma unroll
         for (int q = 0; q < PARTS; ++q)
             *(float4*)(xs + (size_t)q * nch * 4 + (size_t)ci * 4) = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
     }
+    if (g) {
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+    }
     __syncthreads();
+    if (!g) return 1.0f;
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; ++w) tot += red[w];
+    return rsqrtf(tot / (float)p.K + p.eps);
 }
 
 template <typename T>
@@ -366,8 +361,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
     constexpr int EPC = Elt<T>::PER_CHUNK;
     constexpr int R = 4;
     const int nch = p.K / EPC;
-    stage_x<T>(xs, p, nch);
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * GEMV_WAVES + wave, nw = gridDim.x * GEMV_WAVES;
     const T* W = (const T*)p.W;
@@ -376,8 +369,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
         // packed rows: 64-row blocks = [32 gate | 32 up]; one group = 2 outputs (2 gate + 2 up rows)
         const int n_out = p.N >> 1;
         T* y = (T*)p.y;
-        for (int j0 = gw * 2; j0 < n_out; j0 += nw * 2) {
-            const T* rows[R];
+        auto group_rows = [&](int j0, const T* (&rows)[R]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = min(j0 + u, n_out - 1);
@@ -385,15 +377,24 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
                 rows[2 * u] = W + gr * p.ldw;
                 rows[2 * u + 1] = W + (gr + 32) * p.ldw;
             }
-            float acc[R];
-            dot_rows<T, R, true>(rows, xs, nullptr, nch, 0, 1, lane, acc);
+        };
+        const float xscale = stage_x<T>(xs, p, nch);
+        auto finish = [&](int j0, const float (&acc)[R]) {
             if (lane < 2 && j0 + lane < n_out) {
-                const float gt = lane == 0 ? acc[0] : acc[2], up = lane == 0 ? acc[1] : acc[3];
+                const float gt = (lane == 0 ? acc[0] : acc[2]) * xscale, up = (lane == 0 ? acc[1] : acc[3]) * xscale;
                 y[j0 + lane] = from_f32<T>(silu_f(gt) * up);
             }
+        };
+        for (int j0 = gw * 2; j0 < n_out; j0 += nw * 2) {
+            const T* rows[R];
+            group_rows(j0, rows);
+            float acc[R];
+            dot_rows<T, R, true>(rows, xs, nullptr, nch, 0, 1, lane, acc);
+            finish(j0, acc);
         }
         return;
     }
+    const float xscale = stage_x<T>(xs, p, nch);
 
     float best = -INFINITY;
     int best_i = 0x7FFFFFFF;
@@ -403,6 +404,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
         for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, p.N - 1) * p.ldw;
         float acc[R];
         dot_rows<T, R, true>(rows, xs, nullptr, nch, 0, 1, lane, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] *= xscale;
         if (EPI == EPI_ARGMAX) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -428,6 +431,270 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
             p.part_val[blockIdx.x] = v;
             p.part_idx[blockIdx.x] = i;
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ fp8 weight-only variants
+// Opt-in decode mode: the weights are stored as OCP e4m3 bytes with one fp32 scale per output row, the
+// activations stay bf16/fp32.  Same structure as the bf16 kernels above with 16 weights per 16-byte chunk
+// (v_cvt_pk_f32_fp8: 2 weights per instruction), the row scale applied once after the wave reduction.  Halves the HBM bytes of
+// a decode step; VALU work per byte doubles but stays far below the issue limit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+SVLN_DEV void fp8x16_to_f32(const uint4& w, float* f) {
+    const unsigned d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)d[q], false);
+        const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)d[q], true);
+        f[4 * q] = lo[0]; f[4 * q + 1] = lo[1]; f[4 * q + 2] = hi[0]; f[4 * q + 3] = hi[1];
+    }
+}
+// acc (two partial sums) += 16 e4m3 weights . 16 activations, as packed fp32 FMAs (v_pk_fma_f32: the conversion delivers pairs)
+SVLN_DEV void fp8x16_dot(const uint4& w, const f32x2* x2, f32x2& acc) {
+    const unsigned d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)d[q], false);
+        const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)d[q], true);
+        acc = __builtin_elementwise_fma(lo, x2[2 * q], acc);
+        acc = __builtin_elementwise_fma(hi, x2[2 * q + 1], acc);
+    }
+}
+// x (bf16 in global memory) -> LDS fp32 in four 16-byte planes per 16-element chunk: element 16*cj + 4*p + e lives at
+// xs[p * nch8 * 4 + cj * 4 + e], so consecutive lanes read consecutive 16 B in every plane.
+SVLN_DEV float stage_x8(float* xs, const GemvArgs& p, int nch8) {
+    __shared__ float red8[GEMV_WAVES];
+    const bf16* x = (const bf16*)p.x;
+    const bf16* g = (const bf16*)p.norm_w;
+    const int tid = threadIdx.x, nch = p.K / 8;
+    float ss = 0.0f;
+    for (int ci = tid; ci < nch; ci += GEMV_THREADS) {
+        float f[8];
+        chunk_to_f32<bf16>(*(const uint4*)(x + (size_t)ci * 8), f);
+        if (g) {
+            float gf[8];
+            chunk_to_f32<bf16>(*(const uint4*)(g + (size_t)ci * 8), gf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ss = fmaf(f[e], f[e], ss); f[e] *= gf[e]; }
+        }
+        const int cj = ci >> 1, p0 = (ci & 1) * 2;
+        *(float4*)(xs + (size_t)p0 * nch8 * 4 + (size_t)cj * 4) = make_float4(f[0], f[1], f[2], f[3]);
+        *(float4*)(xs + (size_t)(p0 + 1) * nch8 * 4 + (size_t)cj * 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if (g) {
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) red8[tid >> 6] = ss;
+    }
+    __syncthreads();
+    if (!g) return 1.0f;
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; ++w) tot += red8[w];
+    return rsqrtf(tot / (float)p.K + p.eps);     // applied in the epilogue: y = rstd * scale[n] * (Wq . (g * x))
+}
+SVLN_DEV void load_x8(const float* xs, int nch8, int cj, f32x2* x2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *(const float4*)(xs + (size_t)q * nch8 * 4 + (size_t)cj * 4);
+        x2[2 * q] = f32x2{v.x, v.y};
+        x2[2 * q + 1] = f32x2{v.z, v.w};
+    }
+}
+// R dot products of fp8 rows against the LDS copy of x; two chunks per row in flight
+template <int R>
+SVLN_DEV void dot8_rows(const uint8_t* const (&rows)[R], const float* xs, int nch8, int lane, float (&acc)[R]) {
+    f32x2 a2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a2[r] = f32x2{0.0f, 0.0f};
+    int ci = lane;
+    for (; ci + 64 < nch8; ci += 128) {
+        uint4 w0[R], w1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            w0[r] = load_nt(rows[r] + (size_t)ci * 16);
+            w1[r] = load_nt(rows[r] + (size_t)(ci + 64) * 16);
+        }
+        f32x2 x0[8], x1[8];
+        load_x8(xs, nch8, ci, x0);
+        load_x8(xs, nch8, ci + 64, x1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            fp8x16_dot(w0[r], x0, a2[r]);
+            fp8x16_dot(w1[r], x1, a2[r]);
+        }
+    }
+    for (; ci < nch8; ci += 64) {
+        f32x2 x0[8];
+        load_x8(xs, nch8, ci, x0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) fp8x16_dot(load_nt(rows[r] + (size_t)ci * 16), x0, a2[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(a2[r][0] + a2[r][1]);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv8_kernel(GemvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* xs = (float*)smem_raw;
+    constexpr int R = 4;
+    const int nch8 = p.K / 16;
+    const float xscale = stage_x8(xs, p, nch8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * GEMV_WAVES + wave, nw = gridDim.x * GEMV_WAVES;
+    const uint8_t* W = (const uint8_t*)p.w8;
+    if (EPI == EPI_SWIGLU) {
+        const int n_out = p.N >> 1;
+        bf16* y = (bf16*)p.y;
+        for (int j0 = gw * 2; j0 < n_out; j0 += nw * 2) {
+            const uint8_t* rows[R];
+            size_t gr[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = min(j0 + u, n_out - 1);
+                gr[u] = (size_t)(j >> 5) * 64 + (j & 31);
+                rows[2 * u] = W + gr[u] * p.ldw;
+                rows[2 * u + 1] = W + (gr[u] + 32) * p.ldw;
+            }
+            float acc[R];
+            dot8_rows<R>(rows, xs, nch8, lane, acc);
+            if (lane < 2 && j0 + lane < n_out) {
+                const size_t g0 = gr[lane];
+                const float gt = (lane == 0 ? acc[0] : acc[2]) * (p.scale[g0] * xscale), up = (lane == 0 ? acc[1] : acc[3]) * (p.scale[g0 + 32] * xscale);
+                y[j0 + lane] = from_f32<bf16>(silu_f(gt) * up);
+            }
+        }
+        return;
+    }
+    float best = -INFINITY;
+    int best_i = 0x7FFFFFFF;
+    for (int n0 = gw * R; n0 < p.N; n0 += nw * R) {
+        const uint8_t* rows[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, p.N - 1) * p.ldw;
+        float acc[R];
+        dot8_rows<R>(rows, xs, nch8, lane, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] *= p.scale[min(n0 + r, p.N - 1)] * xscale;
+        if (EPI == EPI_ARGMAX) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (n0 + r < p.N && acc[r] > best) { best = acc[r]; best_i = n0 + r; }
+        } else if (lane < R && n0 + lane < p.N) {
+            const int n = n0 + lane;
+            float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+            if (p.bias) v += to_f32(((const bf16*)p.bias)[n]);
+            if (p.res) v += to_f32(((const bf16*)p.res)[n]);
+            ((bf16*)p.y)[n] = from_f32<bf16>(v);
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        __shared__ float bv[GEMV_WAVES];
+        __shared__ int bi[GEMV_WAVES];
+        if (lane == 0) { bv[wave] = best; bi[wave] = best_i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float v = bv[0]; int i = bi[0];
+#pragma unroll
+            for (int w = 1; w < GEMV_WAVES; ++w)
+                if (bv[w] > v || (bv[w] == v && bi[w] < i)) { v = bv[w]; i = bi[w]; }
+            p.part_val[blockIdx.x] = v;
+            p.part_idx[blockIdx.x] = i;
+        }
+    }
+}
+
+// small-N fp8 variant: workgroup = R rows, its 4 waves split K; RMSNorm folded in without a prologue (as gemv_ksplit_kernel)
+template <bool NORM, int R>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv8_ksplit_kernel(GemvArgs p) {
+    __shared__ float part[GEMV_WAVES][R + 1];
+    const int nch8 = p.K / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t* W = (const uint8_t*)p.w8;
+    const bf16* xg = (const bf16*)p.x;
+    const bf16* gg = (const bf16*)p.norm_w;
+    for (int n0 = blockIdx.x * R; n0 < p.N; n0 += gridDim.x * R) {
+        const uint8_t* rows[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, p.N - 1) * p.ldw;
+        float acc[R + 1];
+        f32x2 a2[R];
+#pragma unroll
+        for (int r = 0; r <= R; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) a2[r] = f32x2{0.0f, 0.0f};
+        for (int ci = wave * 64 + lane; ci < nch8; ci += 64 * GEMV_WAVES) {
+            uint4 w[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[r] = load_nt(rows[r] + (size_t)ci * 16);
+            float xf[16];
+            chunk_to_f32<bf16>(*(const uint4*)(xg + (size_t)ci * 16), xf);
+            chunk_to_f32<bf16>(*(const uint4*)(xg + (size_t)ci * 16 + 8), xf + 8);
+            if (NORM) {
+                float gf[16];
+                chunk_to_f32<bf16>(*(const uint4*)(gg + (size_t)ci * 16), gf);
+                chunk_to_f32<bf16>(*(const uint4*)(gg + (size_t)ci * 16 + 8), gf + 8);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[R] = fmaf(xf[e], xf[e], acc[R]); xf[e] *= gf[e]; }
+            }
+            f32x2 x2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x2[e] = f32x2{xf[2 * e], xf[2 * e + 1]};
+#pragma unroll
+            for (int r = 0; r < R; ++r) fp8x16_dot(w[r], x2, a2[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = a2[r][0] + a2[r][1];
+#pragma unroll
+        for (int r = 0; r <= R; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r <= R; ++r) part[wave][r] = acc[r];
+        }
+        __syncthreads();
+        if (threadIdx.x < R && n0 + threadIdx.x < p.N) {
+            const int n = n0 + threadIdx.x;
+            float v = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * p.scale[n];
+            if (NORM) v *= rsqrtf((part[0][R] + part[1][R] + part[2][R] + part[3][R]) / (float)p.K + p.eps);
+            if (p.bias) v += to_f32(((const bf16*)p.bias)[n]);
+            if (p.res) v += to_f32(((const bf16*)p.res)[n]);
+            ((bf16*)p.y)[n] = from_f32<bf16>(v);
+        }
+        __syncthreads();
+    }
+}
+
+// per-row e4m3 quantisation: one workgroup per row, scale = max|w| / 448 (1 for an all-zero row), round-to-nearest-even
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* w, int ld, uint8_t* q, float* scale, int cols) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const bf16* wr = w + row * ld;
+    float amax = 0.0f;
+    for (int ci = threadIdx.x; ci < cols / 8; ci += 256) {
+        float f[8];
+        chunk_to_f32<bf16>(*(const uint4*)(wr + (size_t)ci * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = amax > 0.0f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) scale[row] = sc;
+    const float inv = 1.0f / sc;
+    for (int ci = threadIdx.x; ci < cols / 8; ci += 256) {
+        float f[8];
+        chunk_to_f32<bf16>(*(const uint4*)(wr + (size_t)ci * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * inv, -448.0f), 448.0f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        *(uint2*)(q + row * cols + (size_t)ci * 8) = make_uint2((unsigned)lo, (unsigned)hi);
     }
 }
 
@@ -486,6 +753,25 @@ template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a) { launc
     } while (0)
 template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, hipEvent_t start, hipEvent_t stop) {
     dim3 b(GEMV_THREADS);
+    if (a.w8) {                                   // fp8 weights (bf16 engine only; the engine refuses to enable it otherwise)
+        if (a.epi == EPI_NONE && a.N <= 8192) {
+            constexpr int R = 4;
+            int grid = (a.N + R - 1) / R;
+            if (grid > 2048) grid = 2048;
+            if (a.norm_w) SVLN_LAUNCH((gemv8_ksplit_kernel<true, R>), dim3(grid), b, 0);
+            else SVLN_LAUNCH((gemv8_ksplit_kernel<false, R>), dim3(grid), b, 0);
+            return;
+        }
+        const size_t lds8 = (size_t)a.K * sizeof(float);
+        dim3 g8(gemv_grid(a.N));
+        switch (a.epi) {
+            case EPI_NONE: SVLN_LAUNCH((gemv8_kernel<EPI_NONE>), g8, b, lds8); break;
+            case EPI_SWIGLU: SVLN_LAUNCH((gemv8_kernel<EPI_SWIGLU>), g8, b, lds8); break;
+            case EPI_ARGMAX: SVLN_LAUNCH((gemv8_kernel<EPI_ARGMAX>), g8, b, lds8); break;
+            default: break;
+        }
+        return;
+    }
     if (a.epi == EPI_NONE && a.N <= 8192) {
         static const int r_env = getenv("SVLN_GEMV_R") ? atoi(getenv("SVLN_GEMV_R")) : 0;      // tuning experiments
         const int R = r_env ? r_env : 2;
@@ -543,7 +829,13 @@ template <typename T, int EPI> static void gemv_attr() {
     (void)hipFuncSetAttribute((const void*)gemv_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
 template <typename T> static void gemv_ksplit_attr() {}
+void launch_quant_fp8_rows(hipStream_t s, const void* w_bf16, int ld, void* w8, float* scale, int64_t rows, int cols) {
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, (const bf16*)w_bf16, ld, (uint8_t*)w8, scale, cols);
+}
 void gemv_init_attrs() {
+    (void)hipFuncSetAttribute((const void*)gemv8_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute((const void*)gemv8_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute((const void*)gemv8_kernel<EPI_ARGMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     gemv_ksplit_attr<bf16>(); gemv_ksplit_attr<float>();
     gemv_attr<bf16, EPI_NONE>(); gemv_attr<bf16, EPI_SWIGLU>(); gemv_attr<bf16, EPI_ARGMAX>();
     gemv_attr<float, EPI_NONE>(); gemv_attr<float, EPI_SWIGLU>(); gemv_attr<float, EPI_ARGMAX>();

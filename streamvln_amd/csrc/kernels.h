@@ -45,8 +45,13 @@ struct GemvArgs {
     int N, K;
     int epi;
     float* part_val; int* part_idx;
+    // optional fp8 (OCP e4m3) weight-only path (bf16 engine, opt-in): w8 [N][K] bytes, one fp32 scale per row,
+    // W[n][k] ~= scale[n] * e4m3(w8[n][k]); when set, W is ignored
+    const void* w8; const float* scale;
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
+// per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 16 == 0): scale[r] = max|W[r]| / 448
+void launch_quant_fp8_rows(hipStream_t s, const void* w_bf16, int ld, void* w8, float* scale, int64_t rows, int cols);
 template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, hipEvent_t start, hipEvent_t stop);   // events get the kernel's own begin/end
 int gemv_grid(int N);                       // workgroups launch_gemv uses for N rows
 

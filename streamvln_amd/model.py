@@ -390,6 +390,11 @@ class StreamVLNForCausalLM:
     def set_decode_graph(self, enable: bool):
         _check(self._lib.svln_set_decode_graph(self._h, int(enable)))
 
+    def set_fp8_decode(self, enable: bool):
+        """Opt-in extension (the reference is bf16 only): decode steps and the lm_head read e4m3 copies of the LLM
+        weights (per-row scale).  Prefill, vision and generate_batch keep bf16.  bf16 engines only."""
+        _check(self._lib.svln_set_fp8_decode(self._h, int(enable)))
+
     def sync(self):
         _check(self._lib.svln_sync(self._h))
 

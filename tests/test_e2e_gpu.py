@@ -126,6 +126,55 @@ def test_graph_replay_equals_plain_launches():
         assert np.array_equal(a, b)
 
 
+def test_fp8_decode_weights_opt_in():
+    """SURVEY 8f-2 extension (no reference oracle: the reference is bf16 only).  With e4m3 decode weights the prefill is untouched
+    (bf16), so every turn's first hidden row is bit-identical; decode-step hidden states stay within the e4m3 error level; graph
+    replay equals plain launches; switching it off restores the bf16 results exactly; fp32 engines refuse it."""
+    sc = dict(SCENARIOS["tiny_episode"], eos_mod=0)          # never stop early: several decode steps per turn
+    m = _model(sc, torch.bfloat16)
+    log0, taps0 = _run(m, sc)
+    m.set_fp8_decode(True)
+    runs = []
+    for graph in (True, False):
+        m.set_decode_graph(graph)
+        m.reset(1)
+        log, taps = _run(m, sc)
+        runs.append(([r["out"].sequences[0].tolist() for r in log], [tp["hidden"] for tp in taps], [tp["cache_len"] for tp in taps]))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)
+    assert runs[0][2] == [tp["cache_len"] for tp in taps0]                       # same protocol bookkeeping
+    agree, total, worst = 0, 0, 0.0
+    for t, (h8, tp0, r0) in enumerate(zip(runs[0][1], taps0, log0)):
+        if t == 0:
+            assert np.array_equal(h8[0], tp0["hidden"][0])                       # first turn, first token: prefill only (bf16 in both modes)
+        ids0, ids8 = r0["out"].sequences[0].tolist(), runs[0][0][t]
+        n = 0
+        while n < len(ids0) and ids0[n] == ids8[n]:
+            n += 1
+        agree += n; total += len(ids0)
+        k = min(n + 1, len(ids0))            # rows up to and including the first divergent token saw identical inputs
+        ref = tp0["hidden"][:k].astype(np.float64)
+        worst = max(worst, float(np.linalg.norm(h8[:k] - ref) / np.linalg.norm(ref)))
+        if n < len(ids0):
+            break                             # later turns start from different tokens: not comparable
+    assert worst < 0.08, worst
+    assert total > 0
+    print(f"fp8 decode weights: {agree}/{total} token ids agree with bf16 before the first divergence, hidden rel err {worst:.4f}")
+    m.set_fp8_decode(False)
+    m.set_decode_graph(True)
+    m.reset(1)
+    log1, taps1 = _run(m, sc)
+    assert [r["out"].sequences[0].tolist() for r in log1] == [r["out"].sequences[0].tolist() for r in log0]
+    for a, b in zip(taps0, taps1):
+        assert np.array_equal(a["hidden"], b["hidden"])
+    m.close()
+    m32 = _model(SCENARIOS["tiny_episode"], torch.float32)
+    with pytest.raises(Exception, match="bf16"):
+        m32.set_fp8_decode(True)
+    m32.close()
+
+
 def test_operator_surface_errors():
     sc = SCENARIOS["tiny_episode"]
     m = _model(sc, torch.bfloat16)

@@ -216,6 +216,102 @@ def test_gemv_swiglu_and_argmax(dtype):
     assert tok.value == 77, tok.value
 
 
+def _quant_ref(W):
+    """per-row e4m3 quantisation as the engine does it: scale = amax / 448, q = e4m3(clamp(w * (1 / scale)))"""
+    amax = W.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).to(torch.float32)
+    inv = (1.0 / scale).to(torch.float32)
+    qf = (W * inv[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return qf, scale
+
+
+def test_fp8_row_quantisation_matches_torch_e4m3():
+    """svln_op_quant_fp8 (SURVEY 8f-2 extension): OCP e4m3 bytes and per-row scales equal torch's float8_e4m3fn conversion."""
+    m = engine(TINY, torch.bfloat16)
+    for rows, cols, sd in [(515, 3584, 0.02), (64, 18944, 0.5), (3, 16, 1.0)]:
+        W = q(rnd((rows, cols), 31, sd), torch.bfloat16)
+        W[0] = 0.0                                               # all-zero row: scale 1, bytes 0
+        qf, scale = _quant_ref(W)
+        dW = W.to(torch.bfloat16).cuda()
+        w8 = torch.zeros((rows, cols), dtype=torch.uint8, device="cuda")
+        sc = torch.zeros((rows,), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        chk(m._lib.svln_op_quant_fp8(m._h, ptr(dW), rows, cols, ptr(w8), ptr(sc)))
+        assert torch.equal(sc.cpu(), scale), float((sc.cpu() - scale).abs().max())
+        got, exp = w8.cpu(), qf.view(torch.uint8)
+        got = torch.where(got == 0x80, torch.zeros_like(got), got)      # -0 == +0
+        exp = torch.where(exp == 0x80, torch.zeros_like(exp), exp)
+        assert torch.equal(got, exp), f"{int((got != exp).sum())} of {got.numel()} bytes differ ({rows}x{cols})"
+
+
+@pytest.mark.parametrize("N,K,norm,bias,res", [(4608, 3584, True, True, False), (3584, 18944, False, False, True),
+                                               (515, 512, True, False, True), (7, 64, False, True, False), (9000, 3584, False, False, False)])
+def test_gemv_fp8_weights(N, K, norm, bias, res):
+    """fp8 weight-only GEMV == the same product over the dequantised weights (fp32 accumulate both sides)."""
+    dtype = torch.bfloat16
+    m = engine(TINY, dtype)
+    Wt, x = q(rnd((N, K), 41, 1.0 / math.sqrt(K)), dtype), q(rnd((K,), 42), dtype)
+    g = q(1 + rnd((K,), 43, 0.1), dtype) if norm else None
+    b = q(rnd((N,), 44, 0.1), dtype) if bias else None
+    r = q(rnd((N,), 45), dtype) if res else None
+    qf, scale = _quant_ref(Wt)
+    Wd = qf.to(torch.float32) * scale[:, None]
+    xe = O.rms_norm(x, g, 1e-6) if norm else x
+    exp = Wd @ xe
+    if b is not None:
+        exp = exp + b
+    if r is not None:
+        exp = exp + r
+    d = lambda t: t.to(dtype).cuda() if t is not None else None
+    dx, dg, db, dr = d(x), d(g), d(b), d(r)
+    w8, sc = qf.view(torch.uint8).cuda(), scale.cuda()
+    y = torch.zeros((N,), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv_fp8(m._h, ptr(w8), ptr(sc), K, ptr(dx), ptr(dg), 1e-6, ptr(db), ptr(dr), ptr(y), N, K, _lib.EPI_NONE, None))
+    assert_close(y, exp, dtype, f"gemv fp8 {N}x{K}")
+    # the quantisation error itself stays at the e4m3 level (3 mantissa bits -> ~3 % per weight, averaged down by the dot product)
+    full = Wt @ xe + (b if b is not None else 0) + (r if r is not None else 0)
+    rel = float((exp - full).norm() / full.norm())
+    assert rel < 0.05, rel
+
+
+def test_gemv_fp8_swiglu_and_argmax():
+    dtype = torch.bfloat16
+    m = engine(TINY, dtype)
+    I, K = 1024, 512
+    x = q(rnd((K,), 46), dtype)
+    g = q(1 + rnd((K,), 47, 0.1), dtype)
+    gate, up = q(rnd((I, K), 48, 0.08), dtype), q(rnd((I, K), 49, 0.08), dtype)
+    packed = torch.zeros((2 * I, K))
+    idx = torch.arange(I)
+    packed[(idx // 32) * 64 + idx % 32] = gate
+    packed[(idx // 32) * 64 + 32 + idx % 32] = up
+    qf, scale = _quant_ref(packed)
+    Wd = qf.to(torch.float32) * scale[:, None]
+    xe = O.rms_norm(x, g, 1e-6)
+    gd, ud = Wd[(idx // 32) * 64 + idx % 32], Wd[(idx // 32) * 64 + 32 + idx % 32]
+    exp = O.silu(gd @ xe) * (ud @ xe)
+    y = torch.zeros((I,), dtype=dtype, device="cuda")
+    w8, sc, dx, dg = qf.view(torch.uint8).cuda(), scale.cuda(), x.to(dtype).cuda(), g.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv_fp8(m._h, ptr(w8), ptr(sc), K, ptr(dx), ptr(dg), 1e-6, None, None, ptr(y), 2 * I, K, _lib.EPI_SWIGLU, None))
+    assert_close(y, exp, dtype, "gemv fp8 swiglu")
+    V = 5000
+    Wv = q(rnd((V, K), 50, 0.05), dtype)
+    Wv[77] = q(x * 0.02, dtype)
+    qv, sv = _quant_ref(Wv)
+    logits = (qv.to(torch.float32) * sv[:, None]) @ x
+    tok = C.c_int32(-1)
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv_fp8(m._h, ptr(qv.view(torch.uint8).cuda()), ptr(sv.cuda()), K, ptr(dx), None, 1e-6, None, None, None, V, K,
+                                _lib.EPI_ARGMAX, C.byref(tok)))
+    assert tok.value == int(torch.argmax(logits)) == 77, tok.value
+    # fp32 engines refuse fp8 weights
+    m32 = engine(TINY, torch.float32)
+    rc = m32._lib.svln_op_gemv_fp8(m32._h, ptr(w8), ptr(sc), K, ptr(dx), None, 1e-6, None, None, ptr(y), 2 * I, K, _lib.EPI_NONE, None)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_norms(dtype):
     m = engine(TINY, dtype)
