@@ -12,7 +12,7 @@ and are kept by every config, including TINY.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, asdict
+from dataclasses import dataclass, asdict, replace
 import math
 
 
@@ -100,3 +100,35 @@ MEMORY_TOKEN_INDEX = -300    # streamvln/utils/utils.py:15
 DEFAULT_IMAGE_TOKEN = "<image>"
 DEFAULT_MEMORY_TOKEN = "<memory>"
 DEFAULT_VIDEO_TOKEN = "<video>"
+
+
+def config_from_hf(hf, base: "StreamVLNConfig" = None, name: str = "from_checkpoint") -> "StreamVLNConfig":
+    """Map a checkpoint's HF config (the dict of `config.json`, or the `LlavaQwenConfig` / `AutoConfig` object the reference's
+    harness builds, streamvln_eval.py:521-527) onto StreamVLNConfig.  Only the Qwen2 fields vary between checkpoints of this
+    family; the SigLIP-so400m tower dims are literals in the reference (siglip_encoder.py:73-86) and stay those of `base`.
+    Unsupported structure (head_dim != 128, sliding window, rope scaling, a pooling mode other than bilinear) is an error here
+    rather than a wrong answer on the GPU."""
+    base = base or TRUE
+    get = (lambda k, d=None: hf.get(k, d)) if isinstance(hf, dict) else (lambda k, d=None: getattr(hf, k, d))
+    hidden = int(get("hidden_size", base.hidden))
+    q_heads = int(get("num_attention_heads", base.q_heads))
+    kv_heads = int(get("num_key_value_heads", q_heads))
+    head_dim = int(get("head_dim", None) or hidden // q_heads)
+    if head_dim != 128:
+        raise ValueError(f"head_dim {head_dim} is not supported (the attention kernels are built for 128)")
+    if get("rope_scaling", None) not in (None, {}):
+        raise ValueError("rope_scaling is not supported (the reference forces it to None, stream_video_vln.py:40)")
+    if get("use_sliding_window", False):
+        raise ValueError("sliding-window attention is not supported")
+    mode = get("mm_spatial_pool_mode", "bilinear")
+    if mode != "bilinear":
+        raise ValueError(f"Unexpected mm_spatial_pool_mode: {mode}")       # stream_video_vln.py:69-70
+    ptype = get("mm_projector_type", "mlp2x_gelu")
+    if ptype != "mlp2x_gelu":
+        raise ValueError(f"mm_projector_type {ptype} is not supported (mlp2x_gelu only)")
+    if q_heads % kv_heads != 0 or q_heads // kv_heads > 32:
+        raise ValueError("num_attention_heads must be a multiple of num_key_value_heads with a group size <= 32")
+    return replace(base, name=name, hidden=hidden, layers=int(get("num_hidden_layers", base.layers)), q_heads=q_heads, kv_heads=kv_heads,
+                   head_dim=head_dim, inter=int(get("intermediate_size", base.inter)), vocab=int(get("vocab_size", base.vocab)),
+                   rope_theta=float(get("rope_theta", base.rope_theta)), rms_eps=float(get("rms_norm_eps", base.rms_eps)),
+                   pool_stride=int(get("mm_spatial_pool_stride", base.pool_stride)))

@@ -142,8 +142,23 @@ class StreamVLNForCausalLM:
         if not files:
             raise FileNotFoundError(f"no *.safetensors under {path}")
         from safetensors import safe_open
-        from .config import TRUE
-        m = cls(config if isinstance(config, StreamVLNConfig) else TRUE, dtype=torch_dtype, device=device, **kw)
+        from .config import TRUE, config_from_hf
+        import json
+        # dims: an explicit StreamVLNConfig, else the harness's HF config object, else the checkpoint's config.json, else Qwen2-7B
+        if isinstance(config, StreamVLNConfig):
+            cfg = config
+        elif config is not None:
+            cfg = config_from_hf(config)
+        elif os.path.exists(os.path.join(str(path), "config.json")):
+            cfg = config_from_hf(json.load(open(os.path.join(str(path), "config.json"))))
+        else:
+            cfg = TRUE
+        m = cls(cfg, dtype=torch_dtype, device=device, **kw)
+        gen = os.path.join(str(path), "generation_config.json")
+        if os.path.exists(gen):                                   # stop ids of the checkpoint
+            eos = json.load(open(gen)).get("eos_token_id")
+            if eos is not None:
+                m.generation_config.eos_token_id = list(eos) if isinstance(eos, (list, tuple)) else [int(eos)]
         for f in files:
             with safe_open(f, framework="pt") as sf:
                 for name in sf.keys():

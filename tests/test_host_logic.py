@@ -177,3 +177,20 @@ def test_qwen_prompt_encoder_follows_preprocess_qwen():
     ag = StreamingAgent(FakeModel(), enc, num_frames=8, preprocess=lambda rgb: torch.zeros(3, 4, 4))
     ag.act(0, "go left")
     assert ag.model.calls[0]["inputs"].shape[1] == len(enc(True, False, "go left"))
+
+
+def test_config_from_hf_checkpoint_config():
+    """config.json / AutoConfig of a StreamVLN checkpoint -> StreamVLNConfig (streamvln_eval.py:521-527); unsupported structure raises."""
+    from types import SimpleNamespace
+    from streamvln_amd.config import TRUE, config_from_hf
+    qwen7b = dict(hidden_size=3584, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, intermediate_size=18944,
+                  vocab_size=152064, rope_theta=1000000.0, rms_norm_eps=1e-06, rope_scaling=None, mm_spatial_pool_mode="bilinear",
+                  mm_projector_type="mlp2x_gelu", use_sliding_window=False)
+    c = config_from_hf(qwen7b)
+    assert c.to_dict() == dict(TRUE.to_dict(), name="from_checkpoint")
+    c2 = config_from_hf(SimpleNamespace(**dict(qwen7b, num_hidden_layers=2, vocab_size=4096)))     # attribute-style (AutoConfig)
+    assert (c2.layers, c2.vocab, c2.hidden) == (2, 4096, 3584)
+    for bad in (dict(num_attention_heads=56), dict(rope_scaling={"type": "linear", "factor": 2.0}), dict(mm_spatial_pool_mode="average"),
+                dict(mm_projector_type="linear"), dict(use_sliding_window=True), dict(num_key_value_heads=3)):
+        with pytest.raises(ValueError):
+            config_from_hf(dict(qwen7b, **bad))
