@@ -13,9 +13,12 @@
 //   S^T = K.Q^T on MFMA with the key on the accumulator ROW and the query on the LANE, so the
 //   online-softmax max/sum over keys is an in-lane reduction + ONE cross-half wavefront shuffle
 //   (__shfl_xor 32); P stays in registers and feeds the second MFMA directly as its B operand.
-// Split-KV (decode): grid.z splits write (m, l, unnormalised O) partials; a combine kernel merges.
+// Split-KV (decode, steady prefill with few row blocks, one-frame ViT): grid.z splits write (m, l, unnormalised O)
+// partials (rows padded to 16 bytes, float4 stores); attn_combine_kernel merges them.
 //
-// Roofline: decode = HBM (KV bytes 2*nkv*hd*len*sizeof(T) per layer); prefill/ViT = MFMA.
+// Roofline: decode = HBM (KV bytes 2*nkv*hd*len*sizeof(T) per layer); prefill/ViT = MFMA by flops, but at these sizes
+// (<= 1.2 waves per SIMD) measured ~3 us of exposed latency per 64-key tile: the softmax VALU work, the MFMA chains and the
+// LDS round trips of a wave serialise.
 #include "common.h"
 #include "kernels.h"
 

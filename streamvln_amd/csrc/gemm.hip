@@ -1,23 +1,26 @@
 // MFMA GEMM  C[M,N] = epi(A[M,K] . W[N,K]^T + bias) + res   for the dense QKV / MLP / projector /
 // patch-embed products (prefill and vision; decode uses gemv.hip).
 //
-// One kernel template, two tile configurations (each wave always owns a 64x64 sub-tile = 2x2 MFMA
-// 32x32 accumulators; operands staged global -> registers -> XOR-swizzled LDS, two LDS stages, the
-// loads of stage t+1 issued before the MFMAs of stage t and written after them, one barrier per stage):
-//   * 128x128 tile, 4 waves, 128 B of K per row per stage        -- large M (window-restart prefill, T ~ 1952)
-//   * 256x128 tile, 8 waves, 128 B of K per row per stage, TWO register sets in flight (two stages of HBM latency
-//     tolerance), split-K over grid -- skinny M (steady prefill
-//     T ~ 212, episode start 376, ViT 729 rows): the whole M extent sits in one or a few row tiles so
-//     every weight byte is streamed from HBM once, and K is split so that >= ~256 workgroups exist
-//     (one per CU).  Split-K partials go to fp32 slabs [split][M][N] (plain coalesced stores) and a
-//     second launch sums them and applies the epilogue (bias / GELU / SwiGLU / residual) -- the
-//     launch-boundary reduce, which is cheaper than an in-launch seam at these sizes.
-// LDS rows are 128 B (64 B): the 16-byte chunk index is XOR-swizzled with the row bits above the
-// 256-byte bank row so the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots.
-// Workgroup ids are remapped so that each of the 8 XCDs owns a contiguous band of tiles (operand
-// panels shared through the XCD's private L2).
+// gemm_glds_kernel: MFMA 32x32 accumulators, MI x NJ of them per wave; both operands staged straight into LDS by LDS-DMA
+// (global_load_lds_dwordx4) through a ring of stage buffers (one stage = 128 B of K per tile row), fragment reads by
+// inline-asm ds_read_b128, one s_barrier per stage.  Three tile configurations, picked in launch_epi from M, N:
+//   * Cfg256  256x128, 8 waves (64x64 wave tiles), 3-deep ring, split-K over the grid  -- M <= 256 (steady prefill T ~ 212,
+//     one-frame ViT 729 rows with few column tiles): the whole M extent sits in one row tile so every weight byte is
+//     streamed from HBM once, and K is split so that about one workgroup per CU exists.  Split-K partials go to fp32 slabs
+//     [split][M][N]; a second launch sums them and applies the epilogue (splitk_epilogue_kernel), or -- for o_proj /
+//     down_proj / SigLIP out_proj / fc2 -- also the following RMSNorm / LayerNorm (splitk_rownorm_kernel).
+//   * Cfg128  128x128, 4 waves, 2-deep ring, two workgroups per CU                      -- mid-size M
+//   * CfgBig  256x256, 8 waves (128x64 wave tiles), 2-deep ring                         -- >= 256 such tiles (T ~ 1952,
+//     batched-env prefill, 9-frame ViT)
+// gemm_nt_kernel is the older register-staged form (global -> VGPR -> LDS), kept for callers without a zero line and as a
+// cross-check in the tests (force_cfg | 0x2000).
+// LDS rows are 128 B: the 16-byte chunk index is XOR-swizzled with the row bits above the 256-byte bank row so the 16 lanes
+// of every ds_read_b128 group hit 16 distinct 16-byte slots (the swizzle is applied on the DMA's source address).
+// Workgroup ids are remapped so that each of the 8 XCDs owns a contiguous band of tiles (operand panels shared through the
+// XCD's private L2).
 //
-// Roofline: MFMA-bound for M >= ~512; at M ~ 212 the weight stream (HBM) bounds it.
+// Roofline: MFMA for M >= ~512 (measured ~50 % of dense peak, one stage in flight per CU); at M ~ 212 the L2 -> LDS path
+// (t_stage ~ W_bytes / 6 TB/s + A_bytes / 22.7 TB/s).
 // Algorithmic flops = 2*M*N*K, algorithmic bytes = (M*K + N*K + M*N) * sizeof(T).
 #include "common.h"
 #include "kernels.h"
@@ -607,8 +610,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     //   large M AND N (>= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
     //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel
     const int tilesbig = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    static const int big_min = [] { const char* e = getenv("SVLN_GEMM_BIG_MIN"); return e ? atoi(e) : 256; }();   // tuning knob
-    if ((tilesbig >= big_min && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
+    if ((tilesbig >= 256 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
         a.nsplit = 1;
         a.launch_tiles = tilesbig;
         hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CfgBig, false>), dim3(tilesbig), dim3(CfgBig::THREADS), CfgBig::NBUF * CfgBig::STAGE_BYTES, s, a);

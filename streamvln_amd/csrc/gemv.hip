@@ -2,7 +2,8 @@
 // dominates a batch-1 action-token decode (14.1 GB of bf16 weights per token).
 //
 // Structure (gfx950): 256-thread workgroups; the activation vector is staged ONCE per workgroup
-// into LDS as fp32 (optionally through a fused RMSNorm: sum of squares, rsqrt, gain), then every
+// into LDS as fp32 (with a fused RMSNorm the copy holds g * x and rsqrt(mean x^2 + eps) is applied
+// once per output in the epilogue: one pass over x, one barrier), then every
 // wave streams whole weight rows straight HBM -> VGPR with 16-byte loads (lane i takes chunks
 // i, i+64, ... of the row: each wave instruction reads 1 KiB contiguous), R rows per wave in
 // flight for memory-level parallelism, fp32 FMA accumulate, wave-shuffle reduction, fused epilogue
@@ -773,13 +774,11 @@ template <typename T> void launch_gemv_timed(hipStream_t s, const GemvArgs& a, h
         return;
     }
     if (a.epi == EPI_NONE && a.N <= 8192) {
-        static const int r_env = getenv("SVLN_GEMV_R") ? atoi(getenv("SVLN_GEMV_R")) : 0;      // tuning experiments
-        const int R = r_env ? r_env : 2;
+        constexpr int R = 2;                       // rows per workgroup (R = 4 / 8 measured slower at N <= 8192)
         int grid = (a.N + R - 1) / R;
         if (grid > 2048) grid = 2048;
-        if (R == 2) { if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, 2>), dim3(grid), b, 0); else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, 2>), dim3(grid), b, 0); }
-        else if (R == 8) { if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, 8>), dim3(grid), b, 0); else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, 8>), dim3(grid), b, 0); }
-        else { if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, 4>), dim3(grid), b, 0); else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, 4>), dim3(grid), b, 0); }
+        if (a.norm_w) SVLN_LAUNCH((gemv_ksplit_kernel<T, true, R>), dim3(grid), b, 0);
+        else SVLN_LAUNCH((gemv_ksplit_kernel<T, false, R>), dim3(grid), b, 0);
         return;
     }
     const int grid = gemv_grid(a.N);
