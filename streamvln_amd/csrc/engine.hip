@@ -117,6 +117,7 @@ public:
     int* d_dyn;                  // [0] = position of the token being decoded, [1] = kv_len after it
     // batched (multi-env lockstep) decode
     static constexpr int MAXB = 8;
+    static constexpr int batched_mfma_min = 4;    // measured at B = 8: 340 vs 319 action-steps/s (gate/up 58 vs 97 us per launch)
     DecodeSlot* d_slots = nullptr; DecodeSlot* h_slots = nullptr; int* d_tok_b = nullptr; int* h_tok_b = nullptr;
     float* part_val_b = nullptr; int* part_idx_b = nullptr; T* last_rows = nullptr; int n_generated_b[MAXB] = {0};
     int* d_src; int* h_src;      // splice descriptors
@@ -714,24 +715,39 @@ public:
         launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(V, EPI_ARGMAX, B), B, d_tok_b);
     }
     // One decode step for B envs (B in {1,2,4,8}; d_slots / d_tok_b already set): every weight matrix is streamed once.
+    // B >= 4: the projections run as 32-row MFMA products (gemm.hip CfgSkinny: the weight stream goes through LDS-DMA, the B rows
+    // ride along; the batched GEMV is dot-product-issue bound from B = 4 up) and the split-K reduce of o_proj / down_proj also emits
+    // the following RMSNorm.  B <= 2: the batched GEMV (HBM-bound there).
     void decode_ops_batched(int B) {
         const int qd = nq * 128;
+        const bool mfma = B >= batched_mfma_min;
         launch_gather_rows<T>(st, d_tok_b, embed, feats, x, B, H);
+        bool xn_ready = false;
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
-            // RMSNorm as its own tiny launch in the batched step (amortised over B envs): the GEMVs then run packed bf16 dot
-            // products on the raw activation chunks
-            launch_rmsnorm<T>(st, x, L.in_norm, xn, B, H, c.rms_eps);
-            launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
+            // RMSNorm as its own tiny launch in the batched step (amortised over B envs)
+            if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, B, H, c.rms_eps);
+            if (mfma) launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE));
+            else launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
             AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, qd, 1, 0, 0, true);
             a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr;
             a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * (128 + ATTN_PART_PAD);
             launch_attention<T>(st, a, 128, 1);
             launch_attention_combine<T>(st, a, 128);
-            launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));
-            launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
-            launch_gemv_batched<T>(st, gemvb_args(L.gu_w, H, xn, H, nullptr, nullptr, nullptr, 0, hbuf, I, 2 * I, H, EPI_SWIGLU, B));
-            launch_gemv_batched<T>(st, gemvb_args(L.down_w, I, hbuf, I, nullptr, nullptr, x, H, x, H, H, I, EPI_NONE, B));
+            if (mfma) {
+                GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, B, H, qd, EPI_NONE);
+                ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
+                if (!launch_gemm<T>(st, ao)) launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
+                launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, B, 2 * I, H, EPI_SWIGLU));
+                GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, B, H, I, EPI_NONE);
+                if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
+                xn_ready = launch_gemm<T>(st, ad);
+            } else {
+                launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));
+                launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
+                launch_gemv_batched<T>(st, gemvb_args(L.gu_w, H, xn, H, nullptr, nullptr, nullptr, 0, hbuf, I, 2 * I, H, EPI_SWIGLU, B));
+                launch_gemv_batched<T>(st, gemvb_args(L.down_w, I, hbuf, I, nullptr, nullptr, x, H, x, H, H, I, EPI_NONE, B));
+            }
         }
         head_batched(x, B);
     }

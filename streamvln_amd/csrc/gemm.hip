@@ -46,6 +46,7 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_> 
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2>;
+using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockstep decode of several envs): 2 waves, 20 KB stages, glds kernel only
 using CfgBig4 = TileCfg<256, 256, 2, 2, 128, false, 2>;      // 4 waves, wave tile 128x128 (4x4 accumulators in AGPRs): half the LDS fragment reads per MFMA       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
@@ -577,15 +578,19 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
-    if (a.zeros && !(a.force_cfg & 0x2000))
-        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+    if constexpr (C::MI == 2 && C::NJ == 2) {
+        if (!a.zeros || (a.force_cfg & 0x2000)) {          // register-staged kernel (64x64 wave tiles only)
+            hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
 }
 
-template <typename T, int EPI> bool launch_split(hipStream_t s, GemmArgs a, int S) {
+template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_t s, GemmArgs a, int S) {
+    static_assert(C::BN == Cfg256::BN, "the slab reduce assumes 128-column tiles");
     a.nsplit = S;
-    launch_cfg<T, EPI, Cfg256, true>(s, a, S);
+    launch_cfg<T, EPI, C, true>(s, a, S);
     if (EPI == EPI_NONE && a.norm_out && a.norm_w && a.tile_base == 0 && a.N <= 4096 && a.N % 4 == 0) {
         hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(((a.N / 4 + 63) / 64) * 64), 0, s, a);
         return true;
@@ -609,6 +614,24 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     //   otherwise (few tiles, long K: ViT fc2, o/down at T = 376) -> 256x128 tiles + split-K
     //   large M AND N (>= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
     //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel
+    // M <= 32 (several envs decoded in lockstep): 32x128 tiles, 2 waves, three 20 KB stages in flight per workgroup and two
+    // workgroups per CU -- a weight stream through LDS-DMA with 4 MFMAs per stage, K split when there are few column tiles
+    if (a.M <= 32 && a.zeros && !(a.force_cfg & 0x2000) && ((a.force_cfg & 0xFFF) == 0 || (a.force_cfg & 0xFFF) == 32)) {
+        const int tiles_n = (a.N + 127) / 128;
+        const int stages = (a.K / EPC + CfgSkinny::CH - 1) / CfgSkinny::CH;
+        const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
+        int S = 1;
+        if (a.force_split > 0) S = a.force_split;
+        else if (tiles_n < 192 && can_split) {
+            S = 512 / tiles_n;
+            if (S > stages / 2) S = stages / 2 < 1 ? 1 : stages / 2;
+            if (S > 16) S = 16;
+            while (S > 1 && (size_t)S * a.M * a.N > a.ws_elems) --S;
+        }
+        a.launch_tiles = tiles_n;
+        if (S <= 1) { a.nsplit = 1; launch_cfg<T, EPI, CfgSkinny, false>(s, a, 1); return false; }
+        return launch_split<T, EPI, CfgSkinny>(s, a, S);
+    }
     const int tilesbig = ((a.M + 255) / 256) * ((a.N + 255) / 256);
     if ((tilesbig >= 256 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
         a.nsplit = 1;
@@ -683,6 +706,8 @@ template <typename T, int EPI> static void gemm_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128::NBUF * Cfg128::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::NBUF * CfgBig::STAGE_BYTES);
 }
 void gemm_init_attrs() {

@@ -31,7 +31,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (32, 0), (32, 4)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles; 32 = 32x128 tiles (M <= 32 only)
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -41,6 +41,8 @@ def chk(rc):
     (1, 128, 64, _lib.EPI_NONE, False, False),           # degenerate
 ])
 def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
+    if cfgsplit[0] == 32 and M > 32:
+        M = 8 if M % 2 else 32                        # the 32-row config is chosen for M <= 32 only: rerun the shape with few rows
     m = engine(TINY, dtype)
     A, Wt = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1.0 / math.sqrt(K)), dtype)
     b = q(rnd((N,), 3, 0.1), dtype) if bias else None
