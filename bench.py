@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-feature-cache-pass", action="store_true")
     ap.add_argument("--no-batched-pass", action="store_true")
     ap.add_argument("--no-fp8-pass", action="store_true")
+    ap.add_argument("--no-prune-pass", action="store_true")
     ap.add_argument("--batched-envs", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
@@ -257,6 +258,36 @@ def main():
         fp8 = {"value": round(NUM_FUTURE * a.steps * world / dtf, 2), "ms_per_step": round(dtf / a.steps * 1e3, 3), "dtype": "bf16 activations, e4m3 decode weights",
                "note": "opt-in: decode-step GEMVs and lm_head stream per-row-scaled e4m3 copies of the LLM weights (half the HBM bytes per "
                        "token); prefill and vision stay bf16; reduced precision, not the headline value"}
+    # opt-in slow-memory pruning (BASELINE configs[3] "32 pruned slow-memory tokens"; no reference counterpart, SURVEY a-13): the
+    # `<memory>` block of a window restart is 32 tokens instead of 8 x 196.  Different work -> reported separately, never the headline.
+    pruned = None
+    if not a.no_prune_pass:
+        model.set_feature_cache(0)
+        run.cache_frames = 0
+        model.set_memory_prune(32)
+        while run.step <= EP_STEPS - NUM_FUTURE:
+            run.turn()
+        for _ in range(a.warmup):
+            run.turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0p = time.perf_counter()
+        for _ in range(a.steps):
+            run.turn()
+        model.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtp = time.perf_counter() - t0p
+        if world > 1:
+            tt = torch.tensor([dtp], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtp = float(tt.item())
+        model.set_memory_prune(0)
+        pruned = {"value": round(NUM_FUTURE * a.steps * world / dtp, 2), "ms_per_step": round(dtp / a.steps * 1e3, 3), "keep_tokens": 32,
+                  "note": "opt-in extension (no reference counterpart): <memory> = the 32 history tokens least similar to the mean "
+                          "history token instead of all 8 x 196 (HIP selection kernels, checked against the project's own CPU "
+                          "restatement); changes the model input, not the headline value"}
     # third pass: BASELINE configs[4]-style concurrent envs on this GPU, stepped in lockstep through generate_batch
     # (build-side extension; the headline `value` is the 1-env-per-GPU stream of configs[1]).
     batched = None
@@ -323,6 +354,7 @@ def main():
             "roofline": roof,
             "with_feature_cache": cached,
             "fp8_decode_weights": fp8,
+            "memory_prune_32": pruned,
             "batched_envs": batched,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -93,6 +93,11 @@ int svln_set_decode_graph(svln_engine* h, int enable);     /* replay the per-tok
  * weights (one fp32 scale per output row, quantised on the device from the loaded tensors at the first enable) instead of the bf16
  * ones -- half the HBM bytes per generated token.  bf16 engines only; prefill, vision and svln_generate_batch keep bf16 weights. */
 int svln_set_fp8_decode(svln_engine* h, int enable);
+/* Opt-in slow-memory pruning (BASELINE configs[3]; the reference has NO counterpart -- its memory is all num_history x 196 pooled
+ * tokens, streamvln_eval.py:313-321 -- so this is pinned only by the project's own CPU restatement, oracle: prune_memory_tokens):
+ * with keep_tokens > 0 a `<memory>` sentinel expands to the keep_tokens memory tokens least similar (cosine) to the mean memory
+ * token, in their original order (ties: lower index).  0 (default) = the reference behaviour. */
+int svln_set_memory_prune(svln_engine* h, int keep_tokens);
 int svln_probe_reset(svln_engine* h);
 int svln_probe_read(svln_engine* h, double* total_ms, int64_t* launches, double* bytes_per_launch);
 int svln_phase_times(svln_engine* h, double* vision_ms, double* prefill_ms, double* decode_ms, int reset);
@@ -117,6 +122,9 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
+/* the selection step of svln_set_memory_prune on mem [n_rows][hidden] (engine dtype, device): out_idx[keep] ascending row indices
+ * (host), out_score [n_rows] cosine scores (host, optional) */
+int svln_op_memory_prune(svln_engine* h, const void* mem, int n_rows, int keep, int32_t* out_idx, float* out_score);
 /* fp8 weight-only pieces of svln_set_fp8_decode: per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 16 == 0,
  * scale[r] = max|W[r]| / 448, round to nearest even), and the GEMV over such a matrix (same epilogues as svln_op_gemv) */
 int svln_op_quant_fp8(svln_engine* h, const void* w_bf16, int64_t rows, int cols, void* w8, float* scale);

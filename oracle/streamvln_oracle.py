@@ -197,6 +197,18 @@ def encode_rgbd(w: W, cfg, images: torch.Tensor, time_ids, num_history: Optional
     return img, memory
 
 
+def prune_memory_tokens(mem: torch.Tensor, keep: int):
+    """EXTENSION -- NO REFERENCE COUNTERPART (BASELINE configs[3] "32 pruned slow-memory tokens"): parity
+    unpinned by the reference, this function IS the definition the HIP kernels (misc.hip: mem_*_kernel) are tested against.
+    score_i = cos(mem_i, mean_j mem_j); the `keep` rows with the smallest score survive (ties: lower index), original order.
+    mem [N,H] -> (indices [keep] ascending, scores [N])."""
+    mu = mem.mean(0)
+    score = (mem @ mu) / torch.clamp(mem.norm(dim=1) * mu.norm(), min=1e-20)
+    order = sorted(range(mem.shape[0]), key=lambda i: (float(score[i]), i))
+    idx = torch.tensor(sorted(order[:keep]), dtype=torch.long)
+    return idx, score
+
+
 def splice_embeds(w: W, input_ids: Sequence[int], image_feats, memory_feats) -> torch.Tensor:
     """prepare_inputs_labels_for_multimodal (stream_video_vln.py:182-238), one sample:
     text spans are embedded, each -200 is replaced by the next frame's 196 rows and each
@@ -311,10 +323,11 @@ class OracleStreamVLN:
     """Same call surface as the reference's StreamVLNForCausalLM for the streaming path
     (reset / reset_for_env / generate), computing everything in fp32 on the CPU."""
 
-    def __init__(self, cfg, weights: Dict[str, np.ndarray], num_history: Optional[int] = None):
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], num_history: Optional[int] = None, memory_keep: int = 0):
         self.cfg = cfg
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in weights.items()}
         self.num_history = num_history
+        self.memory_keep = memory_keep          # > 0: opt-in extension prune_memory_tokens (no reference counterpart)
         self.reset(1)
 
     def reset(self, env_num: int):                       # stream_video_vln.py:473-475
@@ -334,6 +347,8 @@ class OracleStreamVLN:
             raise NotImplementedError("single-token `inputs` bypasses the multimodal path in the reference")
         images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
         img, mem = encode_rgbd(w, cfg, images, time_ids, self.num_history)
+        if mem is not None and 0 < self.memory_keep < mem.shape[0]:
+            mem = mem[prune_memory_tokens(mem, self.memory_keep)[0]]
         new = splice_embeds(w, ids, img, mem)
         st = self.cache[env_id]
         st["inputs_embeds"] = new if self.curr_t[env_id] == 0 else torch.cat((st["inputs_embeds"], new), 0)

@@ -54,6 +54,8 @@ SIGNATURES = {
     "svln_get_top2": (_I, [_P, _PF]),
     "svln_set_decode_graph": (_I, [_P, _I]),
     "svln_set_fp8_decode": (_I, [_P, _I]),
+    "svln_set_memory_prune": (_I, [_P, _I]),
+    "svln_op_memory_prune": (_I, [_P, _P, _I, _I, _PI32, _PF]),
     "svln_probe_reset": (_I, [_P]),
     "svln_probe_read": (_I, [_P, _PD, _PI64, _PD]),
     "svln_phase_times": (_I, [_P, _PD, _PD, _PD, _I]),

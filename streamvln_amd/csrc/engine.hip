@@ -65,6 +65,8 @@ struct EngineBase {
     virtual void sync() = 0;
     virtual void set_graph(int enable) = 0;
     virtual void set_fp8_decode(int enable) = 0;
+    virtual void set_memory_prune(int keep) = 0;
+    virtual void op_memory_prune(const void* m, int n_rows, int keep, int32_t* out_idx, float* out_score) = 0;
     virtual void probe_reset() = 0;
     virtual void probe_read(double* ms, int64_t* launches, double* bytes) = 0;
     virtual void phase_times(double* v, double* p, double* d, int reset) = 0;
@@ -121,6 +123,8 @@ public:
     DecodeSlot* d_slots = nullptr; DecodeSlot* h_slots = nullptr; int* d_tok_b = nullptr; int* h_tok_b = nullptr;
     float* part_val_b = nullptr; int* part_idx_b = nullptr; T* last_rows = nullptr; int n_generated_b[MAXB] = {0};
     int* d_src; int* h_src;      // splice descriptors
+    // opt-in slow-memory pruning (no reference counterpart): `<memory>` expands to the prune_keep least-average tokens
+    int prune_keep = 0; float *prune_partial = nullptr, *prune_mean = nullptr, *prune_score = nullptr; int *d_sel = nullptr, *h_sel = nullptr;
     int* h_token;                // pinned
     float* h_top2;
 
@@ -311,6 +315,7 @@ public:
         if (h_hash) (void)hipHostFree(h_hash);
         for (void* p : allocs) (void)hipFree(p);
         (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
+        if (h_sel) (void)hipHostFree(h_sel);
         (void)hipHostFree(h_slots); (void)hipHostFree(h_tok_b);
         (void)hipStreamDestroy(st);
     }
@@ -532,8 +537,15 @@ public:
                 ++img;
             } else if (t == MEMORY_TOKEN) {
                 REQUIRE(n_memory > 0 && mem_used == 0, "<memory> token without (or with repeated) memory frames");
-                REQUIRE(rows + n_memory * otok <= cap, "inputs_embeds exceeds max_positions");
-                for (int j = 0; j < n_memory * otok; ++j) h_src[rows++] = -(1 + frame_base * otok + j);
+                const int nm = n_memory * otok;
+                if (prune_keep > 0 && prune_keep < nm) {          // opt-in: keep the prune_keep least-average memory tokens, in order
+                    REQUIRE(rows + prune_keep <= cap, "inputs_embeds exceeds max_positions");
+                    run_memory_prune(feats + (size_t)frame_base * otok * H, nm, prune_keep);
+                    for (int j = 0; j < prune_keep; ++j) h_src[rows++] = -(1 + frame_base * otok + h_sel[j]);
+                } else {
+                    REQUIRE(rows + nm <= cap, "inputs_embeds exceeds max_positions");
+                    for (int j = 0; j < nm; ++j) h_src[rows++] = -(1 + frame_base * otok + j);
+                }
                 mem_used = 1;
             } else {
                 REQUIRE(t >= 0 && t < V, "token id out of range");
@@ -931,6 +943,33 @@ public:
     void get_top2(float* out) override { out[0] = h_top2[0]; out[1] = h_top2[1]; }
     void sync() override { HIP_CHECK(hipStreamSynchronize(st)); }
     void set_graph(int enable) override { use_graph = enable != 0; if (!use_graph) drop_graphs(); }
+    void ensure_prune_scratch() {
+        if (prune_partial) return;
+        const int nmax = c.max_frames * otok;
+        prune_partial = dalloc<float>((size_t)((nmax + 63) / 64) * H);
+        prune_mean = dalloc<float>(H);
+        prune_score = dalloc<float>(nmax);
+        d_sel = dalloc<int>(nmax);
+        HIP_CHECK(hipHostMalloc((void**)&h_sel, nmax * sizeof(int)));
+    }
+    void set_memory_prune(int keep) override {
+        REQUIRE(keep >= 0, "keep must be >= 0 (0 = the reference behaviour: all num_history x 196 memory tokens)");
+        if (keep > 0) ensure_prune_scratch();
+        prune_keep = keep;
+    }
+    // indices (ascending) of the `keep` rows of m [n_rows][H] (engine dtype, device) that survive; h_sel holds them on return
+    void run_memory_prune(const T* m, int n_rows, int keep) {
+        ensure_prune_scratch();
+        REQUIRE(n_rows >= 1 && n_rows <= c.max_frames * otok && keep >= 1 && keep <= n_rows, "memory prune: bad sizes");
+        launch_memory_prune<T>(st, m, n_rows, H, keep, prune_partial, prune_mean, prune_score, d_sel);
+        HIP_CHECK(hipMemcpyAsync(h_sel, d_sel, keep * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    void op_memory_prune(const void* m, int n_rows, int keep, int32_t* out_idx, float* out_score) override {
+        run_memory_prune((const T*)m, n_rows, keep);
+        for (int j = 0; j < keep; ++j) out_idx[j] = h_sel[j];
+        if (out_score) HIP_CHECK(hipMemcpy(out_score, prune_score, n_rows * sizeof(float), hipMemcpyDeviceToHost));
+    }
     // Opt-in (no reference counterpart): the single-env decode step and the lm_head read e4m3 copies of the LLM
     // weights (per-row scale) instead of the bf16 ones; prefill, vision and the lockstep multi-env path keep bf16.  Both copies stay
     // resident (15.2 + 7.6 GB of 288).  Quantised from the tensors loaded at the time of the first enable.
@@ -1101,6 +1140,10 @@ int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEG
 int svln_get_top2(svln_engine* h, float* out) { API_BEGIN h->impl->get_top2(out); API_END }
 int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN h->impl->set_graph(enable); API_END }
 int svln_set_fp8_decode(svln_engine* h, int enable) { API_BEGIN h->impl->set_fp8_decode(enable); API_END }
+int svln_set_memory_prune(svln_engine* h, int keep_tokens) { API_BEGIN h->impl->set_memory_prune(keep_tokens); API_END }
+int svln_op_memory_prune(svln_engine* h, const void* mem, int n_rows, int keep, int32_t* out_idx, float* out_score) {
+    API_BEGIN h->impl->op_memory_prune(mem, n_rows, keep, out_idx, out_score); API_END
+}
 int svln_probe_reset(svln_engine* h) { API_BEGIN h->impl->probe_reset(); API_END }
 int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN h->impl->probe_read(ms, launches, bytes); API_END }
 int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN h->impl->phase_times(v, p, d, reset); API_END }

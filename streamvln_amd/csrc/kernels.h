@@ -144,6 +144,9 @@ template <typename T> void launch_pool(hipStream_t s, const void* in, void* out,
                                        int side, int out_side, int C);
 
 // out[r][:] = src[r] >= 0 ? embed[src[r]][:] : feats[-(src[r]+1)][:]
+// opt-in slow-memory pruning (misc.hip): sel[0..keep) = ascending indices of the `keep` rows of m [n_rows][H] least similar (cosine) to the mean row
+template <typename T> void launch_memory_prune(hipStream_t s, const void* m, int n_rows, int H, int keep, float* partial, float* mean, float* score,
+                                               int* sel);
 template <typename T> void launch_gather_rows(hipStream_t s, const int* src, const void* embed, const void* feats, void* out,
                                               int rows, int n);
 

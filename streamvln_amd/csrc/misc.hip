@@ -222,6 +222,66 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int* src, const 
     for (int ci = threadIdx.x; ci < n / EPC; ci += 256) *(uint4*)(o + (size_t)ci * EPC) = *(const uint4*)(s + (size_t)ci * EPC);
 }
 
+
+// --------------------------------------------------------------------------- slow-memory token pruning
+// OPT-IN EXTENSION (BASELINE configs[3]; SURVEY.md a-13: the reference has no counterpart, parity is pinned only by this
+// project's own CPU restatement oracle/streamvln_oracle.py: prune_memory_tokens).  Rule: score_i = cos(M_i, mean_j M_j) over the
+// N memory tokens; the `keep` tokens with the SMALLEST score (the least like the average token; ties: lower index) survive,
+// in their original order.  Four launches: column partial sums (64-row blocks, fixed order -> deterministic), mean, per-token
+// score (one wave per token), rank-by-counting selection in one workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void mem_colsum_kernel(const T* m, int n_rows, int H, float* partial) {
+    const int col = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * 64;
+    if (col >= H) return;
+    float acc = 0.0f;
+    for (int r = r0; r < min(r0 + 64, n_rows); ++r) acc += to_f32(m[(size_t)r * H + col]);
+    partial[(size_t)blockIdx.y * H + col] = acc;
+}
+__global__ __launch_bounds__(256) void mem_mean_kernel(const float* partial, int n_blocks, int n_rows, int H, float* mean) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= H) return;
+    float mu = 0.0f;
+    for (int b = 0; b < n_blocks; ++b) mu += partial[(size_t)b * H + col];
+    mean[col] = mu / (float)n_rows;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mem_score_kernel(const T* m, int n_rows, int H, const float* mean, float* score) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    float dot = 0.0f, nn = 0.0f, mm = 0.0f;
+    for (int ci = lane; ci < H / EPC; ci += 64) {
+        float f[EPC];
+        chunk_to_f32<T>(*(const uint4*)(m + (size_t)row * H + (size_t)ci * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float mu = mean[ci * EPC + e];
+            dot = fmaf(f[e], mu, dot); nn = fmaf(f[e], f[e], nn); mm = fmaf(mu, mu, mm);
+        }
+    }
+    dot = wave_sum(dot); nn = wave_sum(nn); mm = wave_sum(mm);
+    if (lane == 0) score[row] = dot / fmaxf(sqrtf(nn) * sqrtf(mm), 1e-20f);
+}
+__global__ __launch_bounds__(1024) void mem_select_kernel(const float* score, int n, int keep, int* sel) {
+    extern __shared__ float sc[];
+    int* flag = (int*)(sc + n);
+    for (int i = threadIdx.x; i < n; i += 1024) sc[i] = score[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float si = sc[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (sc[j] < si || (sc[j] == si && j < i)) ? 1 : 0;
+        flag[i] = rank < keep ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        if (!flag[i]) continue;
+        int pos = 0;
+        for (int j = 0; j < i; ++j) pos += flag[j];
+        sel[pos] = i;
+    }
+}
+
 // ----------------------------------------------------------------------------------------- weights
 SVLN_DEV int64_t map_row(int64_t r, RowMap m) { return (r / m.blk) * (int64_t)m.blk * m.nint + (int64_t)m.phase * m.blk + r % m.blk; }
 
@@ -300,6 +360,15 @@ template <typename T> void launch_gather_rows(hipStream_t s, const int* src, con
     if (rows <= 0) return;
     hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(rows), dim3(256), 0, s, src, (const T*)embed, (const T*)feats, (T*)out, n);
 }
+// scratch: partial [ceil(n/64)][H] floats, mean [H], score [n]; sel [keep] ints (ascending row indices)
+template <typename T> void launch_memory_prune(hipStream_t s, const void* m, int n_rows, int H, int keep, float* partial, float* mean, float* score,
+                                               int* sel) {
+    const int nb = (n_rows + 63) / 64;
+    hipLaunchKernelGGL((mem_colsum_kernel<T>), dim3((H + 255) / 256, nb), dim3(256), 0, s, (const T*)m, n_rows, H, partial);
+    hipLaunchKernelGGL(mem_mean_kernel, dim3((H + 255) / 256), dim3(256), 0, s, partial, nb, n_rows, H, mean);
+    hipLaunchKernelGGL((mem_score_kernel<T>), dim3((n_rows + 3) / 4), dim3(256), 0, s, (const T*)m, n_rows, H, mean, score);
+    hipLaunchKernelGGL(mem_select_kernel, dim3(1), dim3(1024), (size_t)n_rows * 8, s, score, n_rows, keep, sel);
+}
 template <typename T> void launch_synth(hipStream_t s, void* dst, int dst_ld, int64_t rows, int cols, RowMap m, uint64_t seed_t,
                                         float half_width, float base) {
     const float step = half_width / 8388608.0f;
@@ -325,6 +394,7 @@ template <typename T> void launch_from_f32(hipStream_t s, const float* src, void
     template void launch_patchify<T>(hipStream_t, const float*, void*, int, int, int, int);                                       \
     template void launch_pool<T>(hipStream_t, const void*, void*, const int*, const float*, int, int, int, int);                  \
     template void launch_gather_rows<T>(hipStream_t, const int*, const void*, const void*, void*, int, int);                      \
+    template void launch_memory_prune<T>(hipStream_t, const void*, int, int, int, float*, float*, float*, int*);                   \
     template void launch_synth<T>(hipStream_t, void*, int, int64_t, int, RowMap, uint64_t, float, float);                          \
     template void launch_convert<T>(hipStream_t, void*, int, int64_t, int, RowMap, const void*, int);                              \
     template void launch_to_f32<T>(hipStream_t, const void*, float*, int64_t);                                                    \

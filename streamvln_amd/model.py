@@ -405,6 +405,11 @@ class StreamVLNForCausalLM:
     def set_decode_graph(self, enable: bool):
         _check(self._lib.svln_set_decode_graph(self._h, int(enable)))
 
+    def set_memory_prune(self, keep_tokens: int):
+        """Opt-in extension (BASELINE configs[3]; no reference counterpart): `<memory>` expands to the `keep_tokens`
+        memory tokens least similar to the mean memory token instead of all num_history x 196.  0 restores the reference behaviour."""
+        _check(self._lib.svln_set_memory_prune(self._h, int(keep_tokens)))
+
     def set_fp8_decode(self, enable: bool):
         """Opt-in extension (the reference is bf16 only): decode steps and the lm_head read e4m3 copies of the LLM
         weights (per-row scale).  Prefill, vision and generate_batch keep bf16.  bf16 engines only."""

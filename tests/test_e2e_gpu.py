@@ -348,6 +348,42 @@ def test_long_horizon_single_window_vs_live_oracle():
     m.close()
 
 
+def test_memory_prune_extension_vs_live_oracle():
+    """Opt-in slow-memory pruning (BASELINE configs[3]; NO reference counterpart, SURVEY a-13: parity unpinned -- pinned here against
+    the project's own CPU restatement).  Tiny episode with two window restarts, `<memory>` = 40 of the 2 x 196 history tokens: the
+    fp32 engine reproduces the oracle's ids / hidden / cache lengths, the memory turns shrink by exactly 392 - 40 rows, and
+    keep = 0 restores the reference behaviour."""
+    from oracle import streamvln_oracle as O
+    from streamvln_amd import weights as W
+    from scenarios import run_scenario
+    sc = SCENARIOS["tiny_episode"]
+    cfg, keep = sc["cfg"], 40
+    m = _model(sc, torch.float32)
+    m.set_memory_prune(keep)
+    hid = []
+    pre = m.get_vision_tower().image_processor.preprocess_array
+    log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
+    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=sc["num_history"], memory_keep=keep)
+    log_o = run_scenario(orc, sc, preprocess=pre)
+    assert len(log_g) == len(log_o)
+    mem_turns = 0
+    for t, (a, b) in enumerate(zip(log_g, log_o)):
+        assert a["out"].sequences[0].tolist() == b["out"].sequences[0].tolist(), t
+        assert np.abs(hid[t] - b["out"].hidden.numpy()).max() <= HIDDEN_TOL, t
+        assert a["out"].past_key_values.get_seq_length() == b["out"].cache_len, t
+        mem_turns += int(a["memory"])
+    assert mem_turns == 2
+    # same episode without pruning: every memory turn is 2*196 - keep rows longer
+    m.set_memory_prune(0)
+    m.reset(1)
+    log_full = run_scenario(m, sc, preprocess=pre, device="cuda")
+    for a, f in zip(log_g, log_full):
+        if a["memory"]:
+            n_a, n_f = len(a["out"].sequences[0]), len(f["out"].sequences[0])
+            assert f["out"].past_key_values.get_seq_length() - n_f == a["out"].past_key_values.get_seq_length() - n_a + 2 * 196 - keep
+    m.close()
+
+
 def test_eight_envs_round_robin_equal_their_solo_runs():
     """BASELINE configs[4] shape (8 concurrent envs on one GPU): turns of 8 envs interleaved round-robin; every env reproduces
     the token ids it produces when it runs alone (per-env semantics = the batch-1 path)."""

@@ -218,6 +218,29 @@ def test_gemv_swiglu_and_argmax(dtype):
     assert tok.value == 77, tok.value
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,keep", [(588, 32), (392, 40), (70, 69), (5, 1)])
+def test_memory_prune_selection(dtype, N, keep):
+    """svln_op_memory_prune (opt-in extension, no reference counterpart) == oracle.prune_memory_tokens on the same tokens."""
+    m = engine(TINY, dtype)
+    H = TINY.hidden                                          # rows are the engine's hidden width; N <= max_frames * 196
+    mem = q(rnd((N, H), 71) + 0.7 * rnd((1, H), 72) * (1.0 + rnd((N, 1), 73).abs()), dtype)      # a shared component of varying weight
+    mem[3 % N] = mem[0]                                      # an exact tie: the lower index must rank first
+    idx, score = O.prune_memory_tokens(mem, keep)
+    dm = mem.to(dtype).cuda()
+    out_idx = (C.c_int32 * keep)()
+    out_score = np.zeros(N, dtype=np.float32)
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_memory_prune(m._h, ptr(dm), N, keep, out_idx, out_score.ctypes.data_as(C.POINTER(C.c_float))))
+    got = list(out_idx)
+    assert np.abs(out_score - score.numpy()).max() < 2e-5
+    assert got == sorted(got) and len(set(got)) == keep
+    if got != idx.tolist():                                  # only a near-tie at the cut may differ (summation order)
+        cut = sorted(score.tolist())[keep - 1]
+        for i in set(got) ^ set(idx.tolist()):
+            assert abs(float(score[i]) - cut) < 2e-5, (i, float(score[i]), cut)
+
+
 def _quant_ref(W):
     """per-row e4m3 quantisation as the engine does it: scale = amax / 448, q = e4m3(clamp(w * (1 / scale)))"""
     amax = W.abs().amax(dim=1)

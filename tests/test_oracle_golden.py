@@ -67,3 +67,22 @@ def test_pool_restatement_equals_interpolate():
     x = torch.rand(2, 729, 16)
     ref = torch.nn.functional.interpolate(x.view(2, 27, 27, 16).permute(0, 3, 1, 2), size=[14, 14], mode="bilinear")
     assert torch.allclose(O.pool_bilinear(TINY, x), ref.permute(0, 2, 3, 1).reshape(2, 196, 16), atol=1e-5)
+
+
+def test_memory_prune_extension_definition():
+    """prune_memory_tokens (opt-in extension; the reference has no counterpart, SURVEY a-13): keeps the `keep` tokens least similar to
+    the mean token, in order, ties to the lower index; the oracle's memory turns shrink accordingly."""
+    g = torch.Generator().manual_seed(5)
+    mem = torch.randn(50, 16, generator=g) + 2.0
+    mem[7] = -mem[7]                      # the most atypical token
+    mem[20] = mem[10]                     # an exact tie
+    idx, score = O.prune_memory_tokens(mem, 5)
+    assert idx.tolist() == sorted(idx.tolist()) and len(idx) == 5 and 7 in idx.tolist()
+    ref = torch.nn.functional.cosine_similarity(mem, mem.mean(0, keepdim=True), dim=1)
+    assert torch.allclose(score, ref, atol=1e-6)
+    assert set(idx.tolist()) == set(sorted(range(50), key=lambda i: (float(ref[i]), i))[:5])
+    full, _ = O.prune_memory_tokens(mem, 50)
+    assert full.tolist() == list(range(50))
+    k = [i for i in range(50) if float(score[i]) <= float(score[10])]
+    idx2, _ = O.prune_memory_tokens(mem, len(k) - 1)     # cut between the tied pair: 10 stays, 20 goes
+    assert 10 in idx2.tolist() and 20 not in idx2.tolist()
