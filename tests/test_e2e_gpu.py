@@ -204,6 +204,54 @@ def _first_turn_inputs(m, sc, step=0, n_text=24, seed=3):
     return torch.tensor([ids]), img
 
 
+def test_ragged_turns_vs_live_oracle():
+    """Ragged inputs of the splice (stream_video_vln.py:102-291), fp32 engine against the CPU oracle on the same inputs:
+    (a) three frames and three <image> sentinels in ONE turn without memory (V != 1, time_ids[0][0] == 0: every view is an image);
+    (b) a follow-up turn whose only new text is a single token before <image>; (c) a memory turn whose <memory> sentinel comes
+    AFTER its <image>; (d) eos on the very first generated token (one new id, EOS kept, cache length L_total)."""
+    from oracle import streamvln_oracle as O
+    from streamvln_amd import weights as W
+    from streamvln_amd.synthetic import synthetic_frame
+    sc = SCENARIOS["tiny_episode"]
+    cfg = sc["cfg"]
+    m = StreamVLNForCausalLM(cfg, dtype=torch.float32, max_envs=1, max_frames=3, max_positions=2048)
+    m.load_synthetic(SEED)
+    m.model.num_history = 2
+    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=2)
+    pre = m.get_vision_tower().image_processor.preprocess_array
+    frames = torch.stack([pre(synthetic_frame(0, s)) for s in range(5)])               # [5,3,384,384]
+
+    def both(ids, imgs, time_ids, pkv_g, pkv_o, eos=()):
+        g = m.generate(inputs=torch.tensor([ids]), images=imgs[None].cuda(), env_id=0, time_ids=time_ids, max_new_tokens=4, eos_token_ids=list(eos),
+                       past_key_values=pkv_g)
+        hg = m.last_hidden()
+        o = orc.generate(inputs=np.array([ids]), images=imgs[None].numpy(), env_id=0, time_ids=time_ids, max_new_tokens=4, eos_token_ids=list(eos),
+                         past_key_values=pkv_o)
+        assert g.sequences[0].tolist() == o.sequences[0].tolist()
+        assert np.abs(hg - o.hidden.numpy()).max() <= HIDDEN_TOL
+        assert g.past_key_values.get_seq_length() == o.cache_len
+        return g, o
+
+    # (a) three images, no memory
+    ids_a = [11, 12, -200, 13, -200, -200, 14, 15]
+    g, o = both(ids_a, frames[:3], [[0, 1, 2]], None, None)
+    assert g.past_key_values.get_seq_length() == 5 + 3 * 196 + 4 - 1
+    # (b) single text token + image on top of the previous output
+    ids_b = g.sequences[0].tolist() + [21, -200]
+    g, o = both(ids_b, frames[3:4], [[0, 1, 2, 3]], g.past_key_values, o.past_key_values)
+    # (c) window restart with history: <image> first, <memory> after it
+    m.reset_for_env(0); orc.reset_for_env(0)
+    ids_c = [31, -200, 32, -300, 33]
+    g, o = both(ids_c, frames[[0, 2, 4]], [[4]], None, None)
+    assert g.past_key_values.get_seq_length() == 3 + 196 + 2 * 196 + 4 - 1
+    # (d) EOS on the first generated token
+    first = g.sequences[0].tolist()[0]
+    m.reset_for_env(0); orc.reset_for_env(0)
+    g, o = both(ids_c, frames[[0, 2, 4]], [[4]], None, None, eos=(first,))
+    assert g.sequences[0].tolist() == [first] and g.past_key_values.get_seq_length() == 3 + 3 * 196
+    m.close()
+
+
 def test_two_envs_are_isolated():
     """per-env state (embeds, KV pages): interleaving two envs gives each the outputs it has alone"""
     sc = SCENARIOS["tiny_episode"]
