@@ -19,7 +19,7 @@
 // Workgroup ids are remapped so that each of the 8 XCDs owns a contiguous band of tiles (operand panels shared through the
 // XCD's private L2).
 //
-// Roofline: MFMA for M >= ~512 (measured ~50 % of dense peak, one stage in flight per CU); at M ~ 212 the L2 -> LDS path
+// Roofline: MFMA for M >= ~512 (measured 770-990 TF/s, MFMA pipe busy ~45 %: one stage in flight per CU); at M ~ 212 the L2 -> LDS path
 // (t_stage ~ W_bytes / 6 TB/s + A_bytes / 22.7 TB/s).
 // Algorithmic flops = 2*M*N*K, algorithmic bytes = (M*K + N*K + M*N) * sizeof(T).
 #include "common.h"
