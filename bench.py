@@ -11,7 +11,9 @@ size, bf16, seeded random-init weights, synthetic 640x480 RGB stream, 8-frame wi
 (9 frames at a window restart), splice, LLM prefill of the turn's tokens over the retained KV window, 5 greedy
 decode steps.  Turns cycle through 64-env-step episodes: turn 0 = episode start (T=376), turns 1-7 steady
 (T=212), turn 8 = window restart with the 8-frame <memory> block (T=1952, 9 ViT frames), turns 9-15 steady.
-Frames are preprocessed and resident in HBM before the timed region; `value` = 4 * turns / time over all ranks.
+Frames enter as uint8 640x480 host arrays; every env step preprocesses its frame (upload + HIP bicubic resize, bit-exact with the
+reference's PIL path) INSIDE the timed region, as the reference loop does (streamvln_eval.py:271-274); `value` = 4 * turns / time
+over all ranks (frame in -> action ids out).  `generate_boundary` is the same run with the image-processor time taken out.
 
 Extra objects on the JSON line:
   roofline      the gate/up SwiGLU GEMV of the decode step (largest single weight stream: 2*I*H*2 B = 271.6 MB per
@@ -60,21 +62,30 @@ NUM_FRAMES, NUM_FUTURE, NUM_HISTORY, EP_STEPS, DECODE_TOKENS = 32, 4, 8, 64, 5
 
 
 class Runner:
-    """Drives the agent turn by turn on frames that are already resident on the GPU."""
+    """Drives the agent turn by turn from raw uint8 640x480 camera frames (host memory), exactly as the reference loop does:
+    every env step preprocesses its frame (streamvln_eval.py:271-274 -> here upload + HIP bicubic kernel), every 4th step runs a
+    model turn."""
 
     def __init__(self, model, cfg, rank):
         from streamvln_amd.agent import StreamingAgent
         from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
-        proc = model.get_vision_tower().image_processor
-        self.frames = [proc.preprocess_array(synthetic_frame(rank, s)).cuda() for s in range(EP_STEPS)]
-        torch.cuda.synchronize()
+        self.proc = model.get_vision_tower().image_processor
+        assert self.proc.backend == "hip"
+        self.raw = [synthetic_frame(rank, s) for s in range(EP_STEPS)]          # uint8 [480,640,3], host
+        self.pre_s = 0.0                                                        # wall seconds inside the image processor
         self.agent = StreamingAgent(model, SyntheticPromptEncoder(cfg), num_frames=NUM_FRAMES, num_future_steps=NUM_FUTURE,
                                     num_history=NUM_HISTORY, device="cuda", max_new_tokens=DECODE_TOKENS, eos_token_ids=(),
-                                    preprocess=lambda idx: self.frames[idx])
+                                    preprocess=self.preprocess)
         self.step = 0
         self.actions = 0
         self.model = model
         self.cache_frames = 0
+
+    def preprocess(self, idx):
+        t = time.perf_counter()
+        out = self.proc.preprocess_array(self.raw[idx])
+        self.pre_s += time.perf_counter() - t
+        return out
 
     def turn(self):
         """run env steps until one model turn has happened"""
@@ -89,6 +100,31 @@ class Runner:
             self.step += 1
             self.actions += 1
         self.agent.turn_log[:] = self.agent.turn_log[-1:]
+
+
+def timed_pass(model, turn, steps, warmup, world, lat=None):
+    """W untimed turns, then exactly K turns bracketed by barrier + synchronize; returns the MAX-over-ranks seconds."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        turn()
+    model.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        turn()
+        if lat is not None:
+            lat.append(time.perf_counter() - t1)
+    model.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
 
 
 def cpu_baseline(cfg_true):
@@ -161,30 +197,23 @@ def main():
     lib, h = model._lib, model._h
     import ctypes as C
 
+    def finish_episode():
+        while run.step <= EP_STEPS - NUM_FUTURE:    # so the next pass starts on an episode boundary
+            run.turn()                              # (after the last turn of an episode run.step == EP_STEPS - NUM_FUTURE + 1)
+
+    # ---- headline pass: frame in (uint8, host) -> action ids out, everything inside the timed region
     for _ in range(a.warmup):
         run.turn()
     d3 = [C.c_double() for _ in range(3)]
     lib.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 1)
+    model.preprocess_time(reset=True)
+    run.pre_s = 0.0
     if not a.no_probe:
         lib.svln_probe_reset(h)
     lat = []
-    model.sync(); torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    actions0 = run.actions
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        t1 = time.perf_counter()
-        run.turn()
-        lat.append(time.perf_counter() - t1)
-    model.sync(); torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = timed_pass(model, run.turn, a.steps, 0, world, lat)
+    pre_wall_s = run.pre_s
+    pre_gpu_ms, pre_frames = model.preprocess_time(reset=True)
     lib.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 0)
     roof = None
     if not a.no_probe:
@@ -200,105 +229,54 @@ def main():
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)", "achieved": round(ach, 1),
                     "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                     "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
-    # second pass: opt-in frame-feature memoisation.  Reported separately; `value` above re-encodes the
-    # history frames at every window restart exactly as the reference does.
+
+    def extra_pass(setup, teardown):
+        setup()
+        finish_episode()
+        t = timed_pass(model, run.turn, a.steps, a.warmup, world)
+        teardown()
+        return {"value": round(NUM_FUTURE * a.steps * world / t, 2), "ms_per_step": round(t / a.steps * 1e3, 3)}
+
+    # opt-in frame-feature memoisation.  Reported separately; `value` above re-encodes the history frames at every
+    # window restart exactly as the reference does.
     cached = None
     if not a.no_feature_cache_pass:
-        run.cache_frames = 96
-        model.set_feature_cache(96)
-        while run.step <= EP_STEPS - NUM_FUTURE:    # finish the current episode so the pass starts on an episode boundary
-            run.turn()                              # (after the last turn of an episode run.step == EP_STEPS - NUM_FUTURE + 1)
-        for _ in range(a.warmup):
-            run.turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0c = time.perf_counter()
-        for _ in range(a.steps):
-            run.turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dtc = time.perf_counter() - t0c
-        if world > 1:
-            tt = torch.tensor([dtc], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtc = float(tt.item())
+        def on():
+            run.cache_frames = 96
+            model.set_feature_cache(96)
+
+        def off():
+            run.cache_frames = 0
+        cached = extra_pass(on, off)
         hits, misses = model.feature_cache_stats()
-        cached = {"value": round(NUM_FUTURE * a.steps * world / dtc, 2), "ms_per_step": round(dtc / a.steps * 1e3, 3),
-                  "hits": hits, "misses": misses,
-                  "note": "opt-in: pooled features of frames already encoded in the episode are reused (content hash) instead of "
-                          "re-running the ViT on the 8 <memory> frames; not the headline value"}
-    # opt-in fp8 (e4m3) decode weights (no reference counterpart): same stream, decode steps + lm_head read the fp8 copies.
-    # Reduced precision -> reported separately, never the headline value.
+        model.set_feature_cache(0)
+        cached.update(hits=hits, misses=misses,
+                      note="opt-in: pooled features of frames already encoded in the episode are reused (content hash) instead of "
+                           "re-running the ViT on the 8 <memory> frames; not the headline value")
+    # opt-in fp8 (e4m3) decode weights (no reference counterpart).  Reduced precision -> never the headline value.
     fp8 = None
     if not a.no_fp8_pass and a.dtype == "bf16":
-        model.set_feature_cache(0)
-        run.cache_frames = 0
-        model.set_fp8_decode(True)
-        while run.step <= EP_STEPS - NUM_FUTURE:
-            run.turn()
-        for _ in range(a.warmup):
-            run.turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0f = time.perf_counter()
-        for _ in range(a.steps):
-            run.turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dtf = time.perf_counter() - t0f
-        if world > 1:
-            tt = torch.tensor([dtf], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtf = float(tt.item())
-        model.set_fp8_decode(False)
-        fp8 = {"value": round(NUM_FUTURE * a.steps * world / dtf, 2), "ms_per_step": round(dtf / a.steps * 1e3, 3), "dtype": "bf16 activations, e4m3 decode weights",
-               "note": "opt-in: decode-step GEMVs and lm_head stream per-row-scaled e4m3 copies of the LLM weights (half the HBM bytes per "
-                       "token); prefill and vision stay bf16; reduced precision, not the headline value"}
-    # opt-in slow-memory pruning (BASELINE configs[3] "32 pruned slow-memory tokens"; no reference counterpart, SURVEY a-13): the
-    # `<memory>` block of a window restart is 32 tokens instead of 8 x 196.  Different work -> reported separately, never the headline.
+        fp8 = extra_pass(lambda: model.set_fp8_decode(True), lambda: model.set_fp8_decode(False))
+        fp8.update(dtype="bf16 activations, e4m3 decode weights",
+                   note="opt-in: decode-step GEMVs and lm_head stream per-row-scaled e4m3 copies of the LLM weights (half the HBM bytes per "
+                        "token); prefill and vision stay bf16; reduced precision, not the headline value")
+    # opt-in slow-memory pruning (BASELINE configs[3] "32 pruned slow-memory tokens"; no reference counterpart, SURVEY a-13).
     pruned = None
     if not a.no_prune_pass:
-        model.set_feature_cache(0)
-        run.cache_frames = 0
-        model.set_memory_prune(32)
-        while run.step <= EP_STEPS - NUM_FUTURE:
-            run.turn()
-        for _ in range(a.warmup):
-            run.turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0p = time.perf_counter()
-        for _ in range(a.steps):
-            run.turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dtp = time.perf_counter() - t0p
-        if world > 1:
-            tt = torch.tensor([dtp], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtp = float(tt.item())
-        model.set_memory_prune(0)
-        pruned = {"value": round(NUM_FUTURE * a.steps * world / dtp, 2), "ms_per_step": round(dtp / a.steps * 1e3, 3), "keep_tokens": 32,
-                  "note": "opt-in extension (no reference counterpart): <memory> = the 32 history tokens least similar to the mean "
-                          "history token instead of all 8 x 196 (HIP selection kernels, checked against the project's own CPU "
-                          "restatement); changes the model input, not the headline value"}
-    # third pass: BASELINE configs[4]-style concurrent envs on this GPU, stepped in lockstep through generate_batch
-    # (build-side extension; the headline `value` is the 1-env-per-GPU stream of configs[1]).
+        pruned = extra_pass(lambda: model.set_memory_prune(32), lambda: model.set_memory_prune(0))
+        pruned.update(keep_tokens=32,
+                      note="opt-in extension (no reference counterpart): <memory> = the 32 history tokens least similar to the mean "
+                           "history token instead of all 8 x 196 (HIP selection kernels, checked against the project's own CPU "
+                           "restatement); changes the model input, not the headline value")
+    # BASELINE configs[4]-style concurrent envs on this GPU through generate_batch (build-side extension).
     batched = None
     if not a.no_batched_pass and n_benv > 1:
         from streamvln_amd.agent import BatchedAgents, StreamingAgent
         from streamvln_amd.synthetic import SyntheticPromptEncoder
-        model.set_feature_cache(0)
         model.reset(n_benv)
         agents = [StreamingAgent(model, SyntheticPromptEncoder(cfg, seed=7 + 31 * e), num_frames=NUM_FRAMES, num_future_steps=NUM_FUTURE,
                                  num_history=NUM_HISTORY, env_id=e, device="cuda", max_new_tokens=DECODE_TOKENS, eos_token_ids=(),
-                                 preprocess=lambda idx: run.frames[idx]) for e in range(n_benv)]
+                                 preprocess=run.preprocess) for e in range(n_benv)]
         group = BatchedAgents(agents)
         bstep = [0]
 
@@ -313,22 +291,7 @@ def main():
                 bstep[0] += 1
             for ag in agents:
                 ag.turn_log[:] = ag.turn_log[-1:]
-        for _ in range(a.warmup):
-            lockstep_turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0b = time.perf_counter()
-        for _ in range(a.steps):
-            lockstep_turn()
-        model.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dtb = time.perf_counter() - t0b
-        if world > 1:
-            tt = torch.tensor([dtb], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtb = float(tt.item())
+        dtb = timed_pass(model, lockstep_turn, a.steps, a.warmup, world)
         batched = {"envs_per_gpu": n_benv, "value": round(NUM_FUTURE * n_benv * a.steps * world / dtb, 2), "unit": "action-steps/s",
                    "per_gpu": round(NUM_FUTURE * n_benv * a.steps / dtb, 2), "ms_per_lockstep_turn": round(dtb / a.steps * 1e3, 3),
                    "note": "BASELINE configs[4]-style: envs_per_gpu concurrent envs stepped in lockstep (batched prefill rows + batched "
@@ -342,14 +305,23 @@ def main():
             "metric": "action-steps/sec (8-frame window, StreamVLN-Qwen-1.5)", "value": round(value, 2), "unit": "action-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: StreamVLN-Qwen-1.5 (SigLIP-so400m + Qwen2-7B, random-init), synthetic 640x480 stream, "
+            "config": {"workload": "configs[1]: StreamVLN-Qwen-1.5 (SigLIP-so400m + Qwen2-7B, random-init), synthetic uint8 640x480 stream, "
                                    "8-frame window (num_frames 32 / future 4 / history 8), 5 decode tokens/turn, 1 env per GPU; "
-                                   "step = one model turn = 4 actions", "model_config": a.config, "envs_per_gpu": 1,
+                                   "step = one model turn = 4 env steps, each preprocessing its frame (upload + HIP bicubic) inside "
+                                   "the timed region", "model_config": a.config, "envs_per_gpu": 1,
                        "decode_graph": not a.no_graph, "parallelism": f"episode-parallel x{world}"},
             "per_gpu": round(value / world, 2),
             "p50_ms_per_turn": round(float(np.median(lat)) * 1e3, 3),
-            "phase_ms_per_turn": {"vision": round(d3[0].value / a.steps, 3), "prefill": round(d3[1].value / a.steps, 3),
+            # preprocess = wall time inside the image processor (host memcpy to pinned staging + H2D + kernel + sync), 4 frames per turn;
+            # preprocess_gpu = the device part of it (HIP events); vision / prefill / decode = HIP events on the engine's stream
+            "phase_ms_per_turn": {"preprocess": round(pre_wall_s / a.steps * 1e3, 3), "preprocess_gpu": round(pre_gpu_ms / a.steps, 3),
+                                  "vision": round(d3[0].value / a.steps, 3), "prefill": round(d3[1].value / a.steps, 3),
                                   "decode": round(d3[2].value / a.steps, 3)},
+            "preprocess_frames_per_turn": round(pre_frames / a.steps, 2),
+            # the same run with the image-processor time taken out: the rate at the generate() boundary (frames already preprocessed
+            # and resident, as round 1 reported it)
+            "generate_boundary": {"value": round(NUM_FUTURE * turns_total / max(dt - pre_wall_s, 1e-9), 2), "unit": "action-steps/s",
+                                  "ms_per_step": round((dt - pre_wall_s) / a.steps * 1e3, 3)},
             "metric_allreduce_check": summary,
             "roofline": roof,
             "with_feature_cache": cached,

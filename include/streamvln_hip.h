@@ -57,6 +57,14 @@ int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len);
  * pixels fp32 [F,3,S,S] (device or host) -> F*196 pooled rows kept in the engine's frame buffer. */
 int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device);
 
+/* -- image preprocess: SigLipImageProcessor.preprocess (llava/model/multimodal_encoder/siglip_encoder.py:47-67) =
+ * PIL bicubic resize of the camera frame to v_image x v_image (aspect not preserved), x/255, (x - 0.5)/0.5, channels first.
+ * rgb uint8 [n_frames][height][width][3] (host memory, or device memory when on_device) -> out_dev fp32 [n_frames][3][S][S]
+ * (device).  Bit-exact with Pillow's two-pass fixed-point resampler (pillow==11.2.1, requirements.txt:97); complete on return.
+ * svln_preprocess_time: accumulated GPU time (upload + kernel, HIP events) and frame count since the last reset. */
+int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev);
+int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset);
+
 /* -- splice: prepare_inputs_labels_for_multimodal (stream_video_vln.py:182-238) for one env.
  * ids hold text tokens and the sentinels -200 (<image>) / -300 (<memory>); the first n_memory frames
  * of the last svln_encode_frames call form the memory block, the rest are consumed by <image> in order.

@@ -10,8 +10,12 @@ Scenarios
                  (num_frames 12, num_future_steps 4, num_history 2): episode start, steady turns,
                  two window restarts with a 2-frame <memory> block; EOS set = ids % 3 == 2 so
                  turns stop after a varying number of tokens (cap 6).
-  true1_episode  true dimensions, one ViT layer + one LLM layer, vocab 8192: first turn
-                 (181 ids, T=376) + two steady turns (T=212), decode capped at 3 tokens.
+  true1_episode  true dimensions, one ViT layer + one LLM layer, vocab 8192, 36 env steps = 9 turns:
+                 first turn (181 ids, T=376), seven steady turns (T=214) and the window restart at
+                 step 32 (9 views, 1568-row <memory> block, T=1952); decode capped at 3 tokens.
+  true4_episode  true dimensions, 4 ViT + 4 LLM layers, FULL vocabulary 152 064: first turn + one
+                 steady turn, 4 tokens each (inter-layer fused norms, full-size lm_head / arg-max).
+Usage: python -m oracle.make_golden [scenario ... | preprocess]   (default: everything)
 Each scenario is driven through the same `StreamingAgent` twice (reference, oracle); the
 script asserts ids equal and hidden/features within 2e-4 abs+rel before writing.
 """
@@ -73,10 +77,50 @@ def close(a, b, tol=2e-4):
     return np.abs(a - b).max() <= tol * (1.0 + np.abs(b).max())
 
 
+def structured_frames():
+    """640x480 uint8 frames with smooth, saturated and high-contrast content (bicubic overshoot -> clip8 on both ends)."""
+    y, x = np.mgrid[0:480, 0:640]
+    grad = np.stack([(x * 255 // 639), (y * 255 // 479), ((x + y) * 255 // 1118)], -1).astype(np.uint8)
+    checker = (((x // 3 + y // 5) % 2) * 255).astype(np.uint8)[..., None].repeat(3, -1)
+    stripes = np.stack([((x % 7) < 2) * 255, ((y % 4) < 1) * 255, ((x * y) % 256)], -1).astype(np.uint8)
+    return {"grad": grad, "checker": checker, "stripes": stripes}
+
+
+def preprocess_fixture():
+    """G1: image processor pin (siglip_encoder.py:47-67) through the reference's own class: 64 sampled values of frame 0 (as in
+    round 1) plus, for 4 synthetic and 3 structured frames, sha256 of the whole fp32 [3,384,384] output and of its uint8 form
+    (the PIL resize result, CHW), per-channel sums and one full row -- data only."""
+    import hashlib
+    _, _, _, _, Proc = RH.import_reference()
+    from PIL import Image
+    proc = Proc()
+    frames = {f"synthetic_{s}": synthetic_frame(0, s) for s in range(4)}
+    frames.update(structured_frames())
+    fx = {}
+    for k, frame in frames.items():
+        pv = proc.preprocess(images=Image.fromarray(frame).convert("RGB"), return_tensors="pt")["pixel_values"][0].numpy()
+        mine = O.siglip_preprocess(frame)
+        assert np.array_equal(pv, mine), k
+        u8 = np.rint((pv.astype(np.float64) * 0.5 + 0.5) * 255.0).astype(np.uint8)          # CHW uint8 = the PIL resize result
+        fx[f"{k}_sha256_f32"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(pv).tobytes()).digest(), dtype=np.uint8)
+        fx[f"{k}_sha256_u8"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(u8).tobytes()).digest(), dtype=np.uint8)
+        fx[f"{k}_chan_sum_u8"] = u8.reshape(3, -1).astype(np.int64).sum(1)
+        fx[f"{k}_row100_u8"] = u8[:, 100, :].copy()
+        if k == "synthetic_0":
+            idx = np.random.default_rng(5).integers(0, pv.size, 64)
+            fx.update(flat_idx=idx, values=pv.reshape(-1)[idx], sum=np.float64(pv.astype(np.float64).sum()))
+    fx["frame_keys"] = np.asarray(sorted(frames.keys()))
+    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), **fx)
+    print(f"preprocess: exact on {len(frames)} frames")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    want = sys.argv[1:] or list(SCENARIOS) + ["preprocess"]
     for name, sc in SCENARIOS.items():
+        if name not in want:
+            continue
         cfg = sc["cfg"]
         t0 = time.time()
         sd = Wt.synth_state_dict(cfg, SEED, bf16_round=True)
@@ -124,18 +168,12 @@ def main():
                   f"T_embeds {e.shape[0]} ids {ids_r} min-margin {min(o['out'].margins):.4f}")
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
         print(f"{name}: wrote {len(log_r)} turns in {time.time() - t0:.1f}s")
+        del ref, orc, sd, log_r, log_o, emb_r, emb_o
+        import gc
+        gc.collect()
 
-    # G1: image processor pin (siglip_encoder.py:47-67) through the reference's own class
-    _, _, _, _, Proc = RH.import_reference()
-    from PIL import Image
-    frame = synthetic_frame(0, 0)
-    pv = Proc().preprocess(images=Image.fromarray(frame).convert("RGB"), return_tensors="pt")["pixel_values"][0].numpy()
-    mine = O.siglip_preprocess(frame)
-    assert np.array_equal(pv, mine)
-    idx = np.random.default_rng(5).integers(0, pv.size, 64)
-    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), flat_idx=idx, values=pv.reshape(-1)[idx],
-                        sum=np.float64(pv.astype(np.float64).sum()))
-    print("preprocess: exact")
+    if "preprocess" in want:
+        preprocess_fixture()
 
 
 if __name__ == "__main__":

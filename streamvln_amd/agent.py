@@ -76,7 +76,8 @@ class StreamingAgent:
         self.model.reset_for_env(self.env_id)
 
     # -- one model turn ---------------------------------------------------------------
-    def _build_request(self, instruction: str) -> dict:
+    def _build_request(self, instruction: str, env_id: Optional[int] = None) -> dict:
+        env_id = self.env_id if env_id is None else env_id
         first = self.output_ids is None
         with_memory = first and self.step_id != 0
         ids = torch.tensor([self.prompt_encoder(first, with_memory, instruction)], dtype=torch.long)
@@ -96,7 +97,7 @@ class StreamingAgent:
             "images": torch.stack(images).unsqueeze(0).to(self.device).to(self.image_dtype),
             # depths / poses / intrinsics are built by the reference callers and ignored by the model
             "depths": torch.zeros(1, V, 1, 1), "poses": torch.zeros(1, V, 4, 4), "intrinsics": torch.zeros(1, V, 4, 4),
-            "inputs": ids.to(self.device), "env_id": self.env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
+            "inputs": ids.to(self.device), "env_id": env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
             "do_sample": False, "num_beams": 1, "max_new_tokens": self.max_new_tokens, "use_cache": True,
             "return_dict_in_generate": True, "past_key_values": self.past_key_values, "eos_token_ids": self.eos_token_ids,
         }
@@ -108,8 +109,8 @@ class StreamingAgent:
         actions = list(self.decode_actions(out.sequences))
         return actions if len(actions) else [0]               # streamvln_eval.py:340-341
 
-    def _turn(self, instruction: str):
-        return self._consume(self.model.generate(**self._build_request(instruction)))
+    def _turn(self, instruction: str, env_id: Optional[int] = None):
+        return self._consume(self.model.generate(**self._build_request(instruction, env_id)))
 
     # -- split form of act() used by BatchedAgents: observe -> (maybe) request -> finish ----------
     def observe(self, rgb):
@@ -150,7 +151,7 @@ class StreamingAgent:
                 self.past_key_values = None
                 self.time_ids = []
             return None, 0, None
-        actions = self._turn(instruction_text)
+        actions = self._turn(instruction_text, idx)
         return actions, 0.0, self.turn_log[-1]["out"]
 
 

@@ -92,7 +92,11 @@ TINY = StreamVLNConfig(
 #: for true-dim golden vectors.
 TRUE1 = StreamVLNConfig(name="true_dims_1layer", v_layers=1, layers=1, vocab=8192)
 
-CONFIGS = {c.name: c for c in (TRUE, TINY, TRUE1)}
+#: True dimensions, four ViT layers + four LLM layers, FULL vocabulary (152 064): the fused inter-layer hand-offs
+#: (down_proj reduce -> next input_layernorm, fc2 reduce -> next layer_norm1) and the full-size lm_head / arg-max at true width.
+TRUE4 = StreamVLNConfig(name="true_dims_4layer", v_layers=4, layers=4)
+
+CONFIGS = {c.name: c for c in (TRUE, TINY, TRUE1, TRUE4)}
 
 IGNORE_INDEX = -100          # streamvln/utils/utils.py:8
 IMAGE_TOKEN_INDEX = -200     # streamvln/utils/utils.py:9

@@ -35,6 +35,23 @@ static thread_local std::string g_err;
         if (!(c)) throw std::runtime_error(std::string(msg));    \
     } while (0)
 
+// The engine's buffers, stream and launches belong to ONE device; every API call runs with that device current and restores the
+// caller's (torch's) current device on the way out.
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) HIP_CHECK(hipSetDevice(dev));
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+// launches are asynchronous: a bad configuration (LDS size, grid) only shows up in hipGetLastError
+#define LAUNCH_CHECK(what)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = hipGetLastError();                                                             \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(what) + ": kernel launch failed: " + hipGetErrorString(e_)); \
+    } while (0)
+
 constexpr int IMAGE_TOKEN = -200, MEMORY_TOKEN = -300;   // streamvln/utils/utils.py:9,15
 constexpr int PAGE = 64;                                 // keys per KV page
 constexpr int HID_TAP_ROWS = 64;
@@ -54,6 +71,9 @@ struct EngineBase {
     virtual void kv_reset(int env) = 0;
     virtual void env_state(int env, int32_t* n_embeds, int32_t* kv_len) = 0;
     virtual void encode_frames(const float* pixels, int F, int on_device) = 0;
+    virtual void preprocess_frames(const uint8_t* rgb, int n, int height, int width, int on_device, float* out_dev) = 0;
+    virtual void preprocess_time(double* ms, int64_t* frames, int reset) = 0;
+    virtual int device_id() const = 0;
     virtual void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) = 0;
     virtual void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) = 0;
     virtual void generate_batch(const int32_t* envs, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) = 0;
@@ -157,8 +177,10 @@ public:
         if (b) add_slot(name + ".bias", b, out_f, 1, out_f);
     }
 
+    int device_id() const override { return device; }
+
     Engine(const svln_config& cfg, int dev) : c(cfg), device(dev) {
-        HIP_CHECK(hipSetDevice(dev));
+        DeviceGuard guard(dev);
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         Hv = c.v_hidden; Iv = c.v_inter; vheads = c.v_heads; vhd = Hv / vheads; side = c.v_image / c.v_patch; S = side * side;
         kp = ((3 * c.v_patch * c.v_patch + 7) / 8) * 8;
@@ -167,6 +189,7 @@ public:
         REQUIRE(c.head_dim == 128, "LLM head_dim must be 128");
         REQUIRE(vhd == 72, "vision head_dim must be 72");
         REQUIRE(nq % nkv == 0, "q_heads must be a multiple of kv_heads");
+        REQUIRE(nq / nkv <= 32, "at most 32 q heads per kv head (decode attention keeps one GQA group in a 32-row tile)");
         REQUIRE(H % 8 == 0 && I % 32 == 0 && Hv % 8 == 0 && Iv % 8 == 0, "dims must be multiples of 8 (inter of 32)");
         REQUIRE(c.max_positions % PAGE == 0, "max_positions must be a multiple of 64");
         constexpr int EPC = Elt<T>::PER_CHUNK;
@@ -307,8 +330,14 @@ public:
     }
 
     ~Engine() override {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
         (void)hipStreamSynchronize(st);
         drop_graphs();
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (h_rgb) (void)hipHostFree(h_rgb);
+        for (int i = 0; i < 2; ++i) if (pp_ev[i]) (void)hipEventDestroy(pp_ev[i]);
         for (auto e : probe_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
         (void)hipHostFree(h_dyn);
@@ -318,6 +347,7 @@ public:
         if (h_sel) (void)hipHostFree(h_sel);
         (void)hipHostFree(h_slots); (void)hipHostFree(h_tok_b);
         (void)hipStreamDestroy(st);
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
 
     // ------------------------------------------------------------------------------- weights
@@ -520,6 +550,81 @@ public:
         HIP_CHECK(hipEventRecord(ph_ev[1], st));
         vision_pending = true;
         n_feat_frames = F;
+    }
+
+    // ------------------------------------------------------------------------------- a-1: image preprocess on the GPU
+    // SigLipImageProcessor.preprocess (siglip_encoder.py:47-67), bit-exact with Pillow's bicubic (preprocess.hip).  Coefficient tables
+    // are built on the host per frame geometry (double precision, Pillow's operation order) and cached on the device.
+    struct ResampleTabs { int H, W; ResampleDev dev; };
+    std::vector<ResampleTabs> rs_tabs;
+    uint8_t* d_rgb = nullptr; size_t d_rgb_cap = 0; uint8_t* h_rgb = nullptr; size_t h_rgb_cap = 0; float* d_lut = nullptr;
+    hipEvent_t pp_ev[2] = {nullptr, nullptr}; double pp_ms = 0; int64_t pp_frames = 0;
+    const ResampleDev& resample_tabs(int Hh, int Ww) {
+        for (auto& t : rs_tabs) if (t.H == Hh && t.W == Ww) return t.dev;
+        const int Sx = c.v_image;
+        ResampleAxis ah, av;
+        build_resample_table(Ww, Sx, ah);
+        build_resample_table(Hh, Sx, av);
+        auto up = [&](const std::vector<int>& v) {
+            int* d = dalloc<int>(v.size());
+            HIP_CHECK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            return d;
+        };
+        ResampleTabs t; t.H = Hh; t.W = Ww;
+        t.dev.hmin = up(ah.xmin); t.dev.hcnt = up(ah.cnt); t.dev.hk = up(ah.k); t.dev.ks_h = ah.ksize;
+        t.dev.vmin = up(av.xmin); t.dev.vcnt = up(av.cnt); t.dev.vk = up(av.k); t.dev.ks_v = av.ksize;
+        HIP_CHECK(hipStreamSynchronize(st));          // the host vectors go out of scope
+        rs_tabs.push_back(t);
+        return rs_tabs.back().dev;
+    }
+    void preprocess_frames(const uint8_t* rgb, int n, int Hh, int Ww, int on_device, float* out_dev) override {
+        REQUIRE(rgb && out_dev, "null frame / output pointer");
+        REQUIRE(n >= 1 && Hh >= 1 && Ww >= 1, "bad frame geometry");
+        REQUIRE((long long)Hh <= 100ll * Ww, "frames taller than 100 x their width are not supported (Pillow >= 12 resizes them vertical-first)");
+        const int Sx = c.v_image;
+        const size_t bytes = (size_t)n * Hh * Ww * 3;
+        if (!d_lut) {
+            float lut[256];
+            build_normalize_lut(lut, 0.5f, 0.5f);      // image_mean = image_std = 0.5 (siglip_encoder.py:35)
+            d_lut = dalloc<float>(256);
+            HIP_CHECK(hipMemcpy(d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+            for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreate(&pp_ev[i]));
+        }
+        const ResampleDev& tabs = resample_tabs(Hh, Ww);
+        REQUIRE(preprocess_lds_bytes(Ww, Sx, tabs.ks_v) <= (size_t)160 * 1024,
+                "frame too large for the GPU preprocess kernel (its source rows of one output row must fit the 160 KiB LDS)");
+        if (d_rgb_cap < bytes + 64) {
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (d_rgb) HIP_CHECK(hipFree(d_rgb));
+            d_rgb = nullptr; d_rgb_cap = 0;
+            HIP_CHECK(hipMalloc((void**)&d_rgb, bytes + 256));
+            d_rgb_cap = bytes + 256;
+        }
+        HIP_CHECK(hipEventRecord(pp_ev[0], st));
+        if (on_device) {
+            HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, bytes, hipMemcpyDeviceToDevice, st));
+        } else {
+            if (h_rgb_cap < bytes) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (h_rgb) HIP_CHECK(hipHostFree(h_rgb));
+                h_rgb = nullptr; h_rgb_cap = 0;
+                HIP_CHECK(hipHostMalloc((void**)&h_rgb, bytes));
+                h_rgb_cap = bytes;
+            }
+            std::memcpy(h_rgb, rgb, bytes);            // pinned staging: the H2D copy below is a single DMA
+            HIP_CHECK(hipMemcpyAsync(d_rgb, h_rgb, bytes, hipMemcpyHostToDevice, st));
+        }
+        launch_preprocess(st, d_rgb, out_dev, n, Hh, Ww, Sx, tabs, d_lut);
+        LAUNCH_CHECK("preprocess");
+        HIP_CHECK(hipEventRecord(pp_ev[1], st));
+        HIP_CHECK(hipEventSynchronize(pp_ev[1]));     // out_dev is the caller's tensor: complete before any other stream touches it
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, pp_ev[0], pp_ev[1]));
+        pp_ms += t; pp_frames += n;
+    }
+    void preprocess_time(double* ms, int64_t* frames, int reset) override {
+        *ms = pp_ms; *frames = pp_frames;
+        if (reset) { pp_ms = 0; pp_frames = 0; }
     }
 
     // ------------------------------------------------------------------------------- splice
@@ -831,6 +936,7 @@ public:
             std::vector<int> next; std::vector<int> next_tok;
             for (int k = 0; k < Bn; ++k) {
                 const int s = active[k], tok = h_tok_b[k];
+                REQUIRE(tok >= 0 && tok < V, "non-finite logits: the arg-max found no finite value (check the weights / fp8 scales)");
                 if (count[s] < cap) out[(size_t)s * cap + count[s]] = tok;
                 ++count[s];
                 bool stop = count[s] >= max_new || count[s] >= cap;
@@ -893,6 +999,7 @@ public:
         int n = 0;
         while (true) {
             const int tok = read_token();       // synchronises the stream
+            REQUIRE(tok >= 0 && tok < V, "non-finite logits: the arg-max found no finite value (check the weights / fp8 scales)");
             if (n == 0) {
                 float t = 0.f;
                 HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[1] += t;
@@ -1019,6 +1126,11 @@ public:
     // ------------------------------------------------------------------------------- op-level entry points
     bool op_gemm(const GemmArgs& a0) override {
         GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.zeros = zero_line;
+        REQUIRE(a.M >= 0 && a.N >= 0 && a.K >= 0, "negative GEMM extent");
+        if (a.force_split > 1) {
+            REQUIRE((size_t)a.force_split * a.M * a.N <= gemm_ws_elems, "force_split: S * M * N exceeds the split-K workspace");
+            REQUIRE(a.N % 4 == 0 && !(a.epi == EPI_SWIGLU && a.N % 64 != 0), "force_split: N must be a multiple of 4 (64 with SwiGLU)");
+        }
         const bool fused = launch_gemm<T>(st, a);
         sync();
         return fused;
@@ -1083,6 +1195,7 @@ using namespace svln;
 struct svln_engine { EngineBase* impl; };
 
 #define API_BEGIN try {
+#define API_BEGIN_H try { REQUIRE(h && h->impl, "null engine handle"); DeviceGuard guard_(h->impl->device_id());
 #define API_END                                   \
     return 0;                                     \
     }                                             \
@@ -1107,52 +1220,56 @@ int svln_create(const svln_config* cfg, int device, svln_engine** out) {
     *out = h;
     API_END
 }
-void svln_destroy(svln_engine* h) { if (h) { delete h->impl; delete h; } }
-int svln_sync(svln_engine* h) { API_BEGIN h->impl->sync(); API_END }
-int svln_synth_tensor(svln_engine* h, const char* name, uint64_t seed_t, float hw, float base) { API_BEGIN h->impl->synth_tensor(name, seed_t, hw, base); API_END }
+void svln_destroy(svln_engine* h) { if (h) { delete h->impl; delete h; } }       /* ~Engine switches to its device and back */
+int svln_sync(svln_engine* h) { API_BEGIN_H h->impl->sync(); API_END }
+int svln_synth_tensor(svln_engine* h, const char* name, uint64_t seed_t, float hw, float base) { API_BEGIN_H h->impl->synth_tensor(name, seed_t, hw, base); API_END }
 int svln_set_tensor(svln_engine* h, const char* name, const void* data, int dtype, int64_t numel, int on_device) {
-    API_BEGIN h->impl->set_tensor(name, data, dtype, numel, on_device); API_END
+    API_BEGIN_H h->impl->set_tensor(name, data, dtype, numel, on_device); API_END
 }
-int svln_weights_ready(svln_engine* h) { API_BEGIN if (h->impl->weights_missing()) return -2; API_END }
-int svln_get_tensor_f32(svln_engine* h, const char* name, float* out, int64_t numel) { API_BEGIN h->impl->get_tensor_f32(name, out, numel); API_END }
-int svln_reset_env(svln_engine* h, int env) { API_BEGIN h->impl->reset_env(env); API_END }
-int svln_kv_reset(svln_engine* h, int env) { API_BEGIN h->impl->kv_reset(env); API_END }
-int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len) { API_BEGIN h->impl->env_state(env, n_embeds, kv_len); API_END }
-int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device) { API_BEGIN h->impl->encode_frames(pixels, n_frames, on_device); API_END }
-int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory) { API_BEGIN h->impl->append_turn(env, ids, n_ids, 0, n_memory); API_END }
+int svln_weights_ready(svln_engine* h) { API_BEGIN_H if (h->impl->weights_missing()) return -2; API_END }
+int svln_get_tensor_f32(svln_engine* h, const char* name, float* out, int64_t numel) { API_BEGIN_H h->impl->get_tensor_f32(name, out, numel); API_END }
+int svln_reset_env(svln_engine* h, int env) { API_BEGIN_H h->impl->reset_env(env); API_END }
+int svln_kv_reset(svln_engine* h, int env) { API_BEGIN_H h->impl->kv_reset(env); API_END }
+int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len) { API_BEGIN_H h->impl->env_state(env, n_embeds, kv_len); API_END }
+int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device) { API_BEGIN_H h->impl->encode_frames(pixels, n_frames, on_device); API_END }
+int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev) {
+    API_BEGIN_H h->impl->preprocess_frames(rgb, n_frames, height, width, on_device, out_dev); API_END
+}
+int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset) { API_BEGIN_H h->impl->preprocess_time(gpu_ms, frames, reset); API_END }
+int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory) { API_BEGIN_H h->impl->append_turn(env, ids, n_ids, 0, n_memory); API_END }
 int svln_append_turn_at(svln_engine* h, int env, const int64_t* ids, int n_ids, int frame_base, int n_memory) {
-    API_BEGIN h->impl->append_turn(env, ids, n_ids, frame_base, n_memory); API_END
+    API_BEGIN_H h->impl->append_turn(env, ids, n_ids, frame_base, n_memory); API_END
 }
 int svln_generate_batch(svln_engine* h, const int32_t* envs, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap,
                         int32_t* n_out) {
-    API_BEGIN h->impl->generate_batch(envs, n_envs, max_new, eos, n_eos, out, cap, n_out); API_END
+    API_BEGIN_H h->impl->generate_batch(envs, n_envs, max_new, eos, n_eos, out, cap, n_out); API_END
 }
-int svln_get_hidden_batch(svln_engine* h, int slot, float* out, int max_rows, int32_t* n_rows) { API_BEGIN h->impl->get_hidden_batch(slot, out, max_rows, n_rows); API_END }
+int svln_get_hidden_batch(svln_engine* h, int slot, float* out, int max_rows, int32_t* n_rows) { API_BEGIN_H h->impl->get_hidden_batch(slot, out, max_rows, n_rows); API_END }
 int svln_generate(svln_engine* h, int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) {
-    API_BEGIN h->impl->generate(env, max_new, eos, n_eos, out, cap, n_out, false); API_END
+    API_BEGIN_H h->impl->generate(env, max_new, eos, n_eos, out, cap, n_out, false); API_END
 }
 int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out) {
-    API_BEGIN int32_t n = 0; h->impl->generate(env, n_tokens, nullptr, 0, out, n_tokens, &n, true); API_END
+    API_BEGIN_H int32_t n = 0; h->impl->generate(env, n_tokens, nullptr, 0, out, n_tokens, &n, true); API_END
 }
-int svln_get_hidden(svln_engine* h, float* out, int max_rows, int32_t* n_rows) { API_BEGIN h->impl->get_hidden(out, max_rows, n_rows); API_END }
-int svln_get_embeds(svln_engine* h, int env, int start, int n, float* out) { API_BEGIN h->impl->get_embeds(env, start, n, out); API_END }
-int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEGIN h->impl->get_feats(start, n, out); API_END }
-int svln_get_top2(svln_engine* h, float* out) { API_BEGIN h->impl->get_top2(out); API_END }
-int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN h->impl->set_graph(enable); API_END }
-int svln_set_fp8_decode(svln_engine* h, int enable) { API_BEGIN h->impl->set_fp8_decode(enable); API_END }
-int svln_set_memory_prune(svln_engine* h, int keep_tokens) { API_BEGIN h->impl->set_memory_prune(keep_tokens); API_END }
+int svln_get_hidden(svln_engine* h, float* out, int max_rows, int32_t* n_rows) { API_BEGIN_H h->impl->get_hidden(out, max_rows, n_rows); API_END }
+int svln_get_embeds(svln_engine* h, int env, int start, int n, float* out) { API_BEGIN_H h->impl->get_embeds(env, start, n, out); API_END }
+int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEGIN_H h->impl->get_feats(start, n, out); API_END }
+int svln_get_top2(svln_engine* h, float* out) { API_BEGIN_H h->impl->get_top2(out); API_END }
+int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_graph(enable); API_END }
+int svln_set_fp8_decode(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_fp8_decode(enable); API_END }
+int svln_set_memory_prune(svln_engine* h, int keep_tokens) { API_BEGIN_H h->impl->set_memory_prune(keep_tokens); API_END }
 int svln_op_memory_prune(svln_engine* h, const void* mem, int n_rows, int keep, int32_t* out_idx, float* out_score) {
-    API_BEGIN h->impl->op_memory_prune(mem, n_rows, keep, out_idx, out_score); API_END
+    API_BEGIN_H h->impl->op_memory_prune(mem, n_rows, keep, out_idx, out_score); API_END
 }
-int svln_probe_reset(svln_engine* h) { API_BEGIN h->impl->probe_reset(); API_END }
-int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN h->impl->probe_read(ms, launches, bytes); API_END }
-int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN h->impl->phase_times(v, p, d, reset); API_END }
-int svln_set_feature_cache(svln_engine* h, int capacity_frames) { API_BEGIN h->impl->set_feature_cache(capacity_frames); API_END }
-int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses) { API_BEGIN h->impl->feature_cache_stats(hits, misses); API_END }
+int svln_probe_reset(svln_engine* h) { API_BEGIN_H h->impl->probe_reset(); API_END }
+int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN_H h->impl->probe_read(ms, launches, bytes); API_END }
+int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN_H h->impl->phase_times(v, p, d, reset); API_END }
+int svln_set_feature_cache(svln_engine* h, int capacity_frames) { API_BEGIN_H h->impl->set_feature_cache(capacity_frames); API_END }
+int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses) { API_BEGIN_H h->impl->feature_cache_stats(hits, misses); API_END }
 
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                  int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split) {
-    API_BEGIN
+    API_BEGIN_H
     GemmArgs a; std::memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.res_mod = res_mod;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.nsplit = 1; a.force_cfg = force_cfg; a.force_split = force_split;
@@ -1161,7 +1278,7 @@ int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw,
 }
 int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused) {
-    API_BEGIN
+    API_BEGIN_H
     GemmArgs a; std::memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.norm_b = norm_b;
     a.M = M; a.N = N; a.K = K; a.epi = EPI_NONE; a.nsplit = 1; a.force_split = force_split; a.norm_w = norm_w; a.norm_out = norm_out; a.norm_eps = eps;
@@ -1171,33 +1288,33 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
 }
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res, void* y,
                  int N, int K, int epi, int32_t* host_token) {
-    API_BEGIN
+    API_BEGIN_H
     GemvArgs a; a.W = W; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
     a.part_val = nullptr; a.part_idx = nullptr; a.w8 = nullptr; a.scale = nullptr;
     h->impl->op_gemv(a, host_token);
     API_END
 }
 int svln_op_quant_fp8(svln_engine* h, const void* w_bf16, int64_t rows, int cols, void* w8, float* scale) {
-    API_BEGIN h->impl->op_quant_fp8(w_bf16, rows, cols, w8, scale); API_END
+    API_BEGIN_H h->impl->op_quant_fp8(w_bf16, rows, cols, w8, scale); API_END
 }
 int svln_op_gemv_fp8(svln_engine* h, const void* w8, const float* scale, int ldw, const void* x, const void* norm_w, float eps, const void* bias,
                      const void* res, void* y, int N, int K, int epi, int32_t* host_token) {
-    API_BEGIN
+    API_BEGIN_H
     if (K % 16 != 0) throw std::runtime_error("K must be a multiple of 16");
     GemvArgs a; a.W = nullptr; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
     a.part_val = nullptr; a.part_idx = nullptr; a.w8 = w8; a.scale = scale;
     h->impl->op_gemv(a, host_token);
     API_END
 }
-int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps) { API_BEGIN h->impl->op_rmsnorm(x, g, y, rows, n, eps); API_END }
+int svln_op_rmsnorm(svln_engine* h, const void* x, const void* g, void* y, int rows, int n, float eps) { API_BEGIN_H h->impl->op_rmsnorm(x, g, y, rows, n, eps); API_END }
 int svln_op_layernorm(svln_engine* h, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) {
-    API_BEGIN h->impl->op_layernorm(x, g, b, y, rows, n, eps); API_END
+    API_BEGIN_H h->impl->op_layernorm(x, g, b, y, rows, n, eps); API_END
 }
 int svln_op_attention_llm(svln_engine* h, void* qkv, int ld, int T, int P, const void* ctx, int ctx_T, void* out, int o_stride, int nsplit) {
-    API_BEGIN h->impl->op_attention_llm(qkv, ld, T, P, ctx, ctx_T, out, o_stride, nsplit); API_END
+    API_BEGIN_H h->impl->op_attention_llm(qkv, ld, T, P, ctx, ctx_T, out, o_stride, nsplit); API_END
 }
-int svln_op_attention_vit(svln_engine* h, const void* qkv, int ld, int F, void* out, int o_stride) { API_BEGIN h->impl->op_attention_vit(qkv, ld, F, out, o_stride); API_END }
-int svln_op_pool(svln_engine* h, const void* in, void* out, int F) { API_BEGIN h->impl->op_pool(in, out, F); API_END }
-int svln_op_patchify(svln_engine* h, const float* pix, void* out, int F) { API_BEGIN h->impl->op_patchify(pix, out, F); API_END }
+int svln_op_attention_vit(svln_engine* h, const void* qkv, int ld, int F, void* out, int o_stride) { API_BEGIN_H h->impl->op_attention_vit(qkv, ld, F, out, o_stride); API_END }
+int svln_op_pool(svln_engine* h, const void* in, void* out, int F) { API_BEGIN_H h->impl->op_pool(in, out, F); API_END }
+int svln_op_patchify(svln_engine* h, const float* pix, void* out, int F) { API_BEGIN_H h->impl->op_patchify(pix, out, F); API_END }
 
 }  // extern "C"

@@ -640,6 +640,11 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return false;
     constexpr int EPC = Elt<T>::PER_CHUNK;
     a.tile_base = 0;
+    if (a.force_split > 1) {      // a forced split obeys the same workspace / shape limits as the heuristic ones
+        const bool ok = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
+        if (!ok) a.force_split = 1;
+        while (a.force_split > 1 && (size_t)a.force_split * a.M * a.N > a.ws_elems) --a.force_split;
+    }
     // Tile choice (measured on MI355X, tools/kbench.py):
     //   M <= 256            -> 256x128 tiles + split-K: one row tile, every weight byte staged once
     //   M  > 256, >= 96 tiles of 128x128 -> 128x128 tiles, no split (2 workgroups per CU overlap each other's phases)

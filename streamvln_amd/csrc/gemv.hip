@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void argmax_final_batched_kernel(const float* 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out_tokens[blockIdx.x] = si[0];
+    if (threadIdx.x == 0) out_tokens[blockIdx.x] = si[0] == 0x7FFFFFFF ? -1 : si[0];    // no finite logit: -1 (in-range for the next gather, an error on the host)
 }
 
 template <typename T, int EPI>
@@ -724,7 +724,8 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, cons
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *out_token = si[0];
+        *out_token = si[0] == 0x7FFFFFFF ? -1 : si[0];     // no finite logit (NaN / -inf everywhere): -1, which the next embedding gather
+                                                           // reads as frame-feature row 0 (in range) and the host reports as an error
         if (out_top) { out_top[0] = sv[0]; out_top[1] = s2[0]; }
     }
 }

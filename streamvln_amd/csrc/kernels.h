@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace svln {
 
 enum Epi : int { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4 };
@@ -160,10 +162,22 @@ template <typename T> void launch_convert(hipStream_t s, void* dst, int dst_ld, 
 template <typename T> void launch_to_f32(hipStream_t s, const void* src, float* dst, int64_t n);
 template <typename T> void launch_from_f32(hipStream_t s, const float* src, void* dst, int64_t n);
 
+// a-1 on the GPU (preprocess.hip): Pillow's two-pass fixed-point bicubic resize + rescale / normalise, bit-exact.
+// ResampleAxis = the host-built coefficient table of one axis (precompute_coeffs + normalize_coeffs_8bpc of Pillow's Resample.c):
+// for output index i, source taps xmin[i] .. xmin[i]+cnt[i]-1 with 22-bit fixed-point weights k[i*ksize ..].
+struct ResampleAxis { int ksize = 0; std::vector<int> xmin, cnt, k; };
+struct ResampleDev { const int *hmin, *hcnt, *hk, *vmin, *vcnt, *vk; int ks_h, ks_v; };   // device copies (h = along the width, v = along the height)
+void build_resample_table(int in_size, int out_size, ResampleAxis& ax);
+void build_normalize_lut(float* lut256, float mean, float std);
+size_t preprocess_lds_bytes(int W, int S, int ks_v);
+// rgb uint8 [n][H][W][3] (device, readable up to 16 bytes past its end) -> out fp32 [n][3][S][S]
+void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_frames, int H, int W, int S, const ResampleDev& t, const float* lut);
+void preprocess_init_attrs();
+
 // raise the dynamic-LDS limit of the kernels that may ask for more than 64 KiB (call once, outside capture)
 void gemm_init_attrs();
 void gemv_init_attrs();
 void attention_init_attrs();
-inline void init_kernel_attributes() { gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); }
+inline void init_kernel_attributes() { gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); preprocess_init_attrs(); }
 
 }  // namespace svln

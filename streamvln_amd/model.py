@@ -26,17 +26,27 @@ def _check(rc):
 
 
 class SigLipImageProcessor:
-    """llava/model/multimodal_encoder/siglip_encoder.py:34-67: PIL bicubic resize to 384x384
-    (aspect not preserved), x/255, (x-0.5)/0.5, channels first.  Stays on the host: PIL's bicubic
-    is only exactly reproducible on the CPU."""
+    """llava/model/multimodal_encoder/siglip_encoder.py:34-67: bicubic resize to 384x384 (aspect not preserved), x/255,
+    (x-0.5)/0.5, channels first.
 
-    def __init__(self, size=(384, 384)):
+    Two backends with bit-identical results (tests/test_preprocess.py):
+      * "hip"  -- the processor a model hands out (`model.get_vision_tower().image_processor`): upload of the uint8 frame +
+                  one HIP kernel reproducing Pillow's fixed-point bicubic (csrc/preprocess.hip); returns a CUDA tensor, so the
+                  harness's `dict_to_cuda` is a no-op.  No fallback: it raises without the engine / a GPU.
+      * "pil"  -- stand-alone `SigLipImageProcessor()`: Pillow on the host, exactly what the reference runs (host utility
+                  for callers without an engine, and the comparison leg of the tests)."""
+
+    def __init__(self, size=(384, 384), engine=None, device_index: int = 0):
         self.image_mean, self.image_std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)
         self.size = size
         self.rescale_factor = 1 / 255
         self.crop_size = {"height": size[0], "width": size[1]}
+        self._engine = engine                 # (lib, handle) of the owning model
+        self.device_index = device_index
+        self.backend = "hip" if engine is not None else "pil"
 
-    def preprocess_array(self, rgb) -> torch.Tensor:
+    # -- host path (Pillow) ----------------------------------------------------------------------------
+    def _pil(self, rgb) -> torch.Tensor:
         from PIL import Image
         img = rgb if isinstance(rgb, Image.Image) else Image.fromarray(np.asarray(rgb, dtype=np.uint8))
         img = img.convert("RGB").resize((self.size[1], self.size[0]), resample=Image.BICUBIC)
@@ -44,20 +54,53 @@ class SigLipImageProcessor:
         a = (a - np.float32(0.5)) / np.float32(0.5)
         return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
 
+    # -- GPU path --------------------------------------------------------------------------------------
+    @staticmethod
+    def _as_u8(rgb) -> np.ndarray:
+        if not isinstance(rgb, np.ndarray):                       # PIL image (the reference callers pass Image.fromarray(rgb))
+            rgb = np.asarray(rgb.convert("RGB"))
+        a = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError(f"expected an RGB frame [H, W, 3], got shape {a.shape}")
+        return a
+
+    def _hip(self, frames) -> torch.Tensor:
+        """frames: list of uint8 [H,W,3] arrays of one geometry -> CUDA fp32 [n,3,S,S]"""
+        lib, h = self._engine
+        n, (H, W, _) = len(frames), frames[0].shape
+        buf = frames[0] if n == 1 else np.ascontiguousarray(np.stack(frames))
+        dev = torch.device("cuda", self.device_index)
+        out = torch.empty((n, 3, self.size[0], self.size[1]), dtype=torch.float32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()              # the engine writes `out` on its own stream
+        _check(lib.svln_preprocess_frames(h, buf.ctypes.data_as(C.c_void_p), n, H, W, 0, C.c_void_p(out.data_ptr())))
+        return out
+
+    def preprocess_array(self, rgb) -> torch.Tensor:
+        if self.backend == "pil":
+            return self._pil(rgb)
+        return self._hip([self._as_u8(rgb)])[0]
+
     def preprocess(self, images, return_tensors="pt"):
         from PIL import Image
         if isinstance(images, Image.Image) or (isinstance(images, np.ndarray) and images.ndim == 3):
             images = [images]
-        vals = [self.preprocess_array(im) for im in images]
+        if self.backend == "pil":
+            vals = [self._pil(im) for im in images]
+        else:
+            frames = [self._as_u8(im) for im in images]
+            if len({f.shape for f in frames}) == 1:
+                vals = list(self._hip(frames))                    # one upload + one launch for the batch
+            else:
+                vals = [self._hip([f])[0] for f in frames]
         if return_tensors == "pt":
             return {"pixel_values": torch.stack(vals)}
-        return {"pixel_values": [v.numpy() for v in vals]}
+        return {"pixel_values": [v.cpu().numpy() for v in vals]}
 
 
 class _VisionTower:
-    def __init__(self, cfg: StreamVLNConfig):
+    def __init__(self, cfg: StreamVLNConfig, engine=None, device_index: int = 0):
         self.config = SimpleNamespace(hidden_size=cfg.v_hidden, image_size=cfg.v_image, patch_size=cfg.v_patch)
-        self.image_processor = SigLipImageProcessor((cfg.v_image, cfg.v_image))
+        self.image_processor = SigLipImageProcessor((cfg.v_image, cfg.v_image), engine=engine, device_index=device_index)
         self.is_loaded = True
 
     @property
@@ -115,7 +158,7 @@ class StreamVLNForCausalLM:
         _check(lib.svln_create(C.byref(c), device, C.byref(h)))
         self._lib, self._h = lib, h
         self.max_envs, self.max_frames = max_envs, max_frames
-        self._tower = _VisionTower(config)
+        self._tower = _VisionTower(config, engine=(lib, h), device_index=device)
         # `.model` = StreamVLNModel in the reference; callers set `.model.num_history` (streamvln_eval.py:531)
         self.model = SimpleNamespace(num_history=None, get_vision_tower=lambda: self._tower)
         self.config = SimpleNamespace(mm_spatial_pool_mode="bilinear", hidden_size=config.hidden, vocab_size=config.vocab)
@@ -228,17 +271,36 @@ class StreamVLNForCausalLM:
 
     # ---- session state (stream_video_vln.py:473-479) ----------------------------------------------
     def reset(self, env_num: int):
-        if env_num > self.max_envs:
-            raise ValueError(f"env_num {env_num} exceeds the engine's max_envs {self.max_envs}")
+        """`model.reset(world_size)` in the reference harness (streamvln_eval.py:542): sizes the per-env host state.  The
+        reference indexes that state with `env_id = rank` while each process only ever drives ONE env, so `env_num` may
+        exceed the engine's `max_envs`: an env_id is bound to one of the engine's slots on first use, and at most
+        `max_envs` env_ids can be live at a time."""
+        if env_num < 1:
+            raise ValueError("env_num must be >= 1")
         self.curr_t = [0] * env_num
         self._epoch = [0] * env_num
-        for i in range(env_num):
+        self._slots: Dict[int, int] = {}
+        for i in range(self.max_envs):
             _check(self._lib.svln_reset_env(self._h, i))
 
+    def _slot(self, env_id: int) -> int:
+        s = self._slots.get(env_id)
+        if s is None:
+            used = set(self._slots.values())
+            free = [i for i in range(self.max_envs) if i not in used]
+            if not free:
+                raise ValueError(f"env_id {env_id}: all {self.max_envs} engine slots are bound to other envs "
+                                 f"({sorted(self._slots)}); build the model with a larger max_envs")
+            s = self._slots[env_id] = free[0]
+        return s
+
     def reset_for_env(self, env_idx: int):
+        if not (0 <= env_idx < len(self.curr_t)):
+            raise IndexError(f"env_id {env_idx} out of range")
         self.curr_t[env_idx] = 0
         self._epoch[env_idx] += 1
-        _check(self._lib.svln_reset_env(self._h, env_idx))
+        if env_idx in self._slots:
+            _check(self._lib.svln_reset_env(self._h, self._slots[env_idx]))
 
     # ---- the call (stream_video_vln.py:353-407) -------------------------------------------------------
     def _parse_call(self, inputs, images, kwargs):
@@ -283,19 +345,19 @@ class StreamVLNForCausalLM:
     def _begin_turn(self, env_id, past):
         """KV handle / per-env embeds bookkeeping of StreamVLNForCausalLM.generate (stream_video_vln.py:396-401)"""
         if past is None:
-            _check(self._lib.svln_kv_reset(self._h, env_id))
+            _check(self._lib.svln_kv_reset(self._h, self._slot(env_id)))
         elif not isinstance(past, KVHandle) or past.env_id != env_id or past.epoch != self._epoch[env_id]:
             raise ValueError("past_key_values does not belong to this env's current window")
         if self.curr_t[env_id] == 0:
             ne, kl = C.c_int32(), C.c_int32()
-            _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+            _check(self._lib.svln_env_state(self._h, self._slot(env_id), C.byref(ne), C.byref(kl)))
             if ne.value != 0:
-                _check(self._lib.svln_reset_env(self._h, env_id))
+                _check(self._lib.svln_reset_env(self._h, self._slot(env_id)))
         self.curr_t[env_id] += 1
 
     def _result(self, env_id, tokens, inputs):
         ne, kl = C.c_int32(), C.c_int32()
-        _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+        _check(self._lib.svln_env_state(self._h, self._slot(env_id), C.byref(ne), C.byref(kl)))
         dev = inputs.device if isinstance(inputs, torch.Tensor) else "cpu"
         seq = torch.from_numpy(np.asarray(tokens, dtype=np.int64).copy()).unsqueeze(0).to(dev)
         return GenerateOutput(sequences=seq, past_key_values=KVHandle(env_id, self._epoch[env_id], kl.value))
@@ -310,12 +372,12 @@ class StreamVLNForCausalLM:
         _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
         self._begin_turn(env_id, past)
         ids_np = np.ascontiguousarray(ids.numpy())
-        _check(self._lib.svln_append_turn(self._h, env_id, ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
+        _check(self._lib.svln_append_turn(self._h, self._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
         cap = min(max_new, self.cfg.max_positions)
         out = np.zeros(cap, dtype=np.int64)
         n_out = C.c_int32()
         eos_np = np.asarray(eos, dtype=np.int64)
-        _check(self._lib.svln_generate(self._h, env_id, max_new, eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
+        _check(self._lib.svln_generate(self._h, self._slot(env_id), max_new, eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
                                        out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n_out)))
         return self._result(env_id, out[: n_out.value], inputs)
 
@@ -357,10 +419,10 @@ class StreamVLNForCausalLM:
             for (_, ids, _, V, n_memory, env_id, past, _, _) in parsed[i:j]:
                 self._begin_turn(env_id, past)
                 ids_np = np.ascontiguousarray(ids.numpy())
-                _check(self._lib.svln_append_turn_at(self._h, env_id, ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, base, n_memory))
+                _check(self._lib.svln_append_turn_at(self._h, self._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, base, n_memory))
                 base += V
             i = j
-        envs = np.asarray([p[5] for p in parsed], dtype=np.int32)
+        envs = np.asarray([self._slot(p[5]) for p in parsed], dtype=np.int32)
         cap = min(max_new, self.cfg.max_positions)
         out = np.zeros((len(parsed), cap), dtype=np.int64)
         n_out = np.zeros(len(parsed), dtype=np.int32)
@@ -385,13 +447,19 @@ class StreamVLNForCausalLM:
 
     def env_state(self, env_id=0):
         ne, kl = C.c_int32(), C.c_int32()
-        _check(self._lib.svln_env_state(self._h, env_id, C.byref(ne), C.byref(kl)))
+        _check(self._lib.svln_env_state(self._h, self._slot(env_id), C.byref(ne), C.byref(kl)))
         return ne.value, kl.value
 
     def get_embeds(self, env_id, start, n) -> np.ndarray:
         out = np.empty((n, self.cfg.hidden), dtype=np.float32)
-        _check(self._lib.svln_get_embeds(self._h, env_id, start, n, out.ctypes.data_as(C.POINTER(C.c_float))))
+        _check(self._lib.svln_get_embeds(self._h, self._slot(env_id), start, n, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def preprocess_time(self, reset: bool = False):
+        """(GPU ms, frames) spent in the image processor's HIP path since the last reset"""
+        ms, n = C.c_double(), C.c_int64()
+        _check(self._lib.svln_preprocess_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
 
     def set_feature_cache(self, capacity_frames: int):
         """Memoise pooled frame features by pixel content (opt-in; 0 = re-encode every frame like the reference)."""

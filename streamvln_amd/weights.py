@@ -142,11 +142,14 @@ def tensor_specs(cfg: StreamVLNConfig) -> List[TensorSpec]:
     return s
 
 
-def synth_tensor(spec: TensorSpec, seed: int, bf16_round: bool = True) -> np.ndarray:
-    v = synth_flat(tensor_seed(seed, spec.name), 0, spec.numel, spec.half_width, spec.base)
-    if bf16_round:
-        v = round_to_bf16(v)
-    return v.reshape(spec.shape)
+def synth_tensor(spec: TensorSpec, seed: int, bf16_round: bool = True, chunk: int = 1 << 24) -> np.ndarray:
+    seed_t = tensor_seed(seed, spec.name)
+    out = np.empty(spec.numel, dtype=np.float32)
+    for s0 in range(0, spec.numel, chunk):                  # chunked: the 545 M-element vocab tensors stay within a few 100 MB of scratch
+        n = min(chunk, spec.numel - s0)
+        v = synth_flat(seed_t, s0, n, spec.half_width, spec.base)
+        out[s0:s0 + n] = round_to_bf16(v) if bf16_round else v
+    return out.reshape(spec.shape)
 
 
 def synth_state_dict(cfg: StreamVLNConfig, seed: int, bf16_round: bool = True,

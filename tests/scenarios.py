@@ -3,7 +3,7 @@ parity tests (test infrastructure)."""
 import torch
 
 from streamvln_amd.agent import StreamingAgent
-from streamvln_amd.config import TINY, TRUE1
+from streamvln_amd.config import TINY, TRUE1, TRUE4
 from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
 
 SEED = 1234
@@ -12,8 +12,12 @@ SCENARIOS = {
     # 36 env steps = 9 model turns over 3 windows; EOS set = ids % 3 == 2 (varying turn lengths, cap 6)
     "tiny_episode": dict(cfg=TINY, steps=36, num_frames=12, nfs=4, num_history=2, max_new=6, eos_mod=3,
                          lens=(40, 48, 16)),
-    # true dimensions, one ViT layer + one LLM layer: first turn (T=376) + two steady turns (T=214), 3 tokens each
-    "true1_episode": dict(cfg=TRUE1, steps=12, num_frames=32, nfs=4, num_history=8, max_new=3, eos_mod=0,
+    # true dimensions, one ViT layer + one LLM layer, 36 env steps = 9 turns: first turn (T=376), seven steady turns (T=214) and the
+    # window restart at step 32 (9 views: 8 history frames -> 1568-row <memory> block + current frame, T=1952), 3 tokens each
+    "true1_episode": dict(cfg=TRUE1, steps=36, num_frames=32, nfs=4, num_history=8, max_new=3, eos_mod=0,
+                          lens=(181, 190, 16)),
+    # true dimensions, 4 ViT + 4 LLM layers, full vocabulary (152 064): first turn + one steady turn, 4 tokens each
+    "true4_episode": dict(cfg=TRUE4, steps=8, num_frames=32, nfs=4, num_history=8, max_new=4, eos_mod=0,
                           lens=(181, 190, 16)),
 }
 

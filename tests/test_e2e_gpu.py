@@ -34,8 +34,10 @@ def _run(m, sc, device="cuda"):
     return log, taps
 
 
-@pytest.mark.parametrize("name", ["tiny_episode", "true1_episode"])
+@pytest.mark.parametrize("name", ["tiny_episode", "true1_episode", "true4_episode"])
 def test_fp32_parity_vs_reference_golden(name):
+    """true1_episode runs through the window restart at true width (9-frame ViT batch, 1568-row <memory> block, T = 1952);
+    true4_episode has 4 ViT + 4 LLM layers at true width and the full 152 064-entry vocabulary (fused inter-layer norms, lm_head)."""
     sc, g = SCENARIOS[name], load_golden(name)
     m = _model(sc, torch.float32)
     embeds = []
@@ -73,25 +75,45 @@ def test_fp32_parity_vs_reference_golden(name):
     m.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_episode", "true1_episode"])
+# bf16 shipping mode against the fp32 reference fixture.  The hidden state is a unit-RMS vector after the final norm; with bf16
+# storage of activations between ~10 kernels per layer its error grows like sqrt(depth) * 2^-9.  BF16_HIDDEN_REL bounds the relative
+# L2 error of EVERY comparable hidden row (rows of a turn up to and including the first token that differs from the fixture: they saw
+# identical inputs); measured values are printed.  Token ids must agree wherever the fixture's top-2 logit margin exceeds
+# BF16_MARGIN (logit error of a bf16 run ~ |h| * |w| * 2^-8 ~ 0.02 here).
+BF16_HIDDEN_REL = {"tiny_episode": 1.2e-2, "true1_episode": 8e-3, "true4_episode": 1.2e-2}
+BF16_MARGIN = 0.05
+
+
+@pytest.mark.parametrize("name", ["tiny_episode", "true1_episode", "true4_episode"])
 def test_bf16_mode_vs_golden(name):
     sc, g = SCENARIOS[name], load_golden(name)
     m = _model(sc, torch.bfloat16)
     log, taps = _run(m, sc)
-    agree = total = 0
+    agree = total = rows = 0
+    worst = 0.0
+    diverged = False
     for t, rec in enumerate(log):
         ids = rec["out"].sequences[0].tolist()
         gold = g[f"t{t}_ids"].tolist()
         margins = g[f"t{t}_margins"]
-        # first token of the turn is comparable even if later ones diverge
-        total += 1
-        agree += int(ids[0] == gold[0])
-        if margins[0] > 0.05:
-            assert ids[0] == gold[0], (name, t, ids, gold, margins)
-        h, gh = taps[t]["hidden"][0], g[f"t{t}_hidden"][0]
-        rel = np.linalg.norm(h - gh) / np.linalg.norm(gh)
-        assert rel < 3e-2, (name, t, rel)
-    assert agree >= total - 1, (agree, total)
+        n = 0
+        while n < min(len(ids), len(gold)) and ids[n] == gold[n]:
+            n += 1
+        k = min(n + 1, len(gold), len(ids))                 # comparable rows of this turn
+        if not diverged:
+            for j in range(k):
+                h, gh = taps[t]["hidden"][j], g[f"t{t}_hidden"][j]
+                rel = float(np.linalg.norm(h - gh) / np.linalg.norm(gh))
+                worst = max(worst, rel); rows += 1
+                assert rel < BF16_HIDDEN_REL[name], (name, t, j, rel)
+                if j < len(margins) and margins[j] > BF16_MARGIN:
+                    assert ids[j] == gold[j], (name, t, j, ids, gold, margins)
+            total += len(gold); agree += n
+            if n < len(gold):
+                diverged = True                               # later turns start from different generated ids: not comparable
+    assert rows >= 1
+    print(f"bf16 vs fp32 fixture [{name}]: {rows} hidden rows compared, worst rel L2 error {worst:.2e}, "
+          f"{agree}/{total} ids agree before the first divergence")
     m.close()
 
 
@@ -175,6 +197,35 @@ def test_fp8_decode_weights_opt_in():
     m32.close()
 
 
+def test_reference_harness_env_ids_map_onto_engine_slots():
+    """The reference harness calls model.reset(world_size) and drives env_id = rank (streamvln_eval.py:225,324,542,553) in a process
+    that owns ONE env: an engine with max_envs = 1 must accept reset(8) + generate(env_id=7), and refuse a second live env."""
+    sc, g = SCENARIOS["tiny_episode"], load_golden("tiny_episode")
+    m = _model(sc, torch.float32)
+    m.reset(8)
+    proc = m.get_vision_tower().image_processor
+    from scenarios import run_scenario as rs
+    from streamvln_amd.agent import StreamingAgent
+    from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+    enc = SyntheticPromptEncoder(sc["cfg"], seed=7, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
+    ag = StreamingAgent(m, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"], num_history=sc["num_history"], env_id=7,
+                        max_new_tokens=sc["max_new"], eos_token_ids=eos_ids(sc), preprocess=proc.preprocess_array, device="cuda")
+    for step in range(16):                                    # 4 turns incl. the first window restart, all as env 7
+        ag.act(synthetic_frame(0, step))
+    for t, rec in enumerate(ag.turn_log):
+        assert rec["out"].sequences[0].tolist() == g[f"t{t}_ids"].tolist(), t
+        assert rec["out"].past_key_values.env_id == 7
+    img = torch.zeros(1, 1, 3, 384, 384)
+    with pytest.raises(ValueError, match="slots"):
+        m.generate(inputs=torch.tensor([[5, 6, -200, 7]]), images=img, env_id=3, time_ids=[[0]], max_new_tokens=1)   # a second live env
+    with pytest.raises(IndexError):
+        m.generate(inputs=torch.tensor([[5, 6, -200, 7]]), images=img, env_id=8, time_ids=[[0]], max_new_tokens=1)
+    m.reset(2)                                               # a new reset frees the binding
+    out = m.generate(inputs=torch.tensor([[5, 6, -200, 7]]), images=img, env_id=1, time_ids=[[0]], max_new_tokens=1, eos_token_ids=[])
+    assert out.sequences.shape == (1, 1)
+    m.close()
+
+
 def test_operator_surface_errors():
     sc = SCENARIOS["tiny_episode"]
     m = _model(sc, torch.bfloat16)
@@ -225,7 +276,7 @@ def test_ragged_turns_vs_live_oracle():
         g = m.generate(inputs=torch.tensor([ids]), images=imgs[None].cuda(), env_id=0, time_ids=time_ids, max_new_tokens=4, eos_token_ids=list(eos),
                        past_key_values=pkv_g)
         hg = m.last_hidden()
-        o = orc.generate(inputs=np.array([ids]), images=imgs[None].numpy(), env_id=0, time_ids=time_ids, max_new_tokens=4, eos_token_ids=list(eos),
+        o = orc.generate(inputs=np.array([ids]), images=imgs[None].cpu().numpy(), env_id=0, time_ids=time_ids, max_new_tokens=4, eos_token_ids=list(eos),
                          past_key_values=pkv_o)
         assert g.sequences[0].tolist() == o.sequences[0].tolist()
         assert np.abs(hg - o.hidden.numpy()).max() <= HIDDEN_TOL

@@ -194,3 +194,71 @@ def test_config_from_hf_checkpoint_config():
                 dict(mm_projector_type="linear"), dict(use_sliding_window=True), dict(num_key_value_heads=3)):
         with pytest.raises(ValueError):
             config_from_hf(dict(qwen7b, **bad))
+
+
+def test_agent_reproduces_the_reference_callers_generate_calls():
+    """tests/golden/agent_calls.npz = every generate(**kwargs) the REFERENCE's VLNEvaluator.step issued over 44 env steps driven as
+    its HTTP server drives it (oracle/make_agent_calls.py; streamvln_agent.py:169-258, http_realworld_server.py:95-112).
+    StreamingAgent.step + QwenPromptEncoder(flavour="agent") must issue the same calls: ids incl. sentinels, views (which frames,
+    by pixel sum), time_ids, past_key_values None / not, flags, reset points and returned action sequences."""
+    from stub_tokenizer import RecordingModel, StubTokenizer
+    from streamvln_amd.prompt import QwenPromptEncoder
+    g = np.load(os.path.join(ROOT, "tests", "golden", "agent_calls.npz"))
+    num_frames, nfs, nh = (int(v) for v in g["config"])
+    tok = StubTokenizer()
+    model = RecordingModel(SigLipImageProcessor())
+    enc = QwenPromptEncoder(tok, flavour="agent")
+    ag = StreamingAgent(model, enc, num_frames=num_frames, num_future_steps=nfs, num_history=nh, image_dtype=torch.bfloat16,
+                        decode_actions=lambda seq: parse_actions(tok.batch_decode(seq)[0].strip()))
+    n_resets0 = len(model.resets)                       # the constructor's reset_memory (the reference does not reset at construction)
+    returned = []
+    instruction = str(g["instruction"])
+    for s in range(int(g["n_steps"])):
+        acts, _, _ = ag.step(0, synthetic_frame(0, s), instruction, run_model=(ag.step_id % 4 == 0))
+        returned.append([] if acts is None else list(acts))
+        ag.step_id += 1
+    assert len(model.calls) == int(g["n_calls"])
+    for k, c in enumerate(model.calls):
+        for name, v in c.items():
+            exp = g[f"c{k}_{name}"]
+            assert np.array_equal(np.asarray(v), exp), (k, name, v, exp)
+    assert np.array_equal(np.asarray(model.resets[n_resets0:], dtype=np.int64).reshape(-1, 2), g["resets"])
+    assert [len(r) for r in returned] == g["returned_len"].tolist()
+    assert [a for r in returned for a in r] == g["returned_flat"].tolist()
+    assert (g["c8_inputs"] == MEMORY_TOKEN_INDEX).sum() == 1 and int(g["c8_views"]) == 1 + nh     # the window-restart call is in the fixture
+
+
+def test_run_sharded_resumes_by_skipping_finished_episodes(tmp_path):
+    """resume contract of streamvln_eval.py:203-224,365-377: result.json is append-only; a restarted run skips the
+    (scene, episode, instruction) triples already present, rank 0 reloads their metrics, the summary covers all episodes."""
+    import json
+    from types import SimpleNamespace
+    from streamvln_amd.eval_harness import load_done, run_sharded
+    eps = {sc: [SimpleNamespace(episode_id=f"{sc}-{i}", instruction_text=f"go {i}") for i in range(3)] for sc in ("b_scene", "a_scene")}
+    path = str(tmp_path / "out" / "result.json")
+    ran = []
+
+    class Interrupted(RuntimeError):
+        pass
+
+    def run_episode(scene, ep, limit=[4]):
+        if len(ran) >= limit[0]:
+            raise Interrupted()
+        ran.append(ep.episode_id)
+        i = int(ep.episode_id[-1])
+        return {"success": float(i % 2), "spl": 0.25 * i, "os": 1.0, "ne": 1.0 + i, "steps": 10 + i}
+
+    with pytest.raises(Interrupted):                                   # first run dies after 4 of 6 episodes
+        run_sharded(eps, run_episode, result_path=path)
+    done, metrics = load_done(path)
+    assert [d[1] for d in done] == ["a_scene-0", "a_scene-1", "a_scene-2", "b_scene-0"] and len(metrics) == 4     # scenes in sorted order
+    first = list(ran)
+    ran.clear()
+    summary = run_sharded(eps, lambda s, e: run_episode(s, e, limit=[99]), result_path=path)
+    assert ran == ["b_scene-1", "b_scene-2"] and not set(ran) & set(first)                                        # only the unfinished ones ran
+    assert summary["length"] == 6 and abs(summary["sucs_all"] - 2 / 6) < 1e-12 and abs(summary["ones_all"] - 2.0) < 1e-12
+    lines = [json.loads(l) for l in open(path)]
+    assert len(lines) == 7 and "scene_id" not in lines[-1] and lines[-1]["length"] == 6                           # 6 episode records + summary
+    ran.clear()
+    again = run_sharded(eps, lambda s, e: run_episode(s, e, limit=[99]), result_path=path)                         # nothing left to do
+    assert ran == [] and again["length"] == 6

@@ -216,6 +216,32 @@ def test_gemv_swiglu_and_argmax(dtype):
     torch.cuda.synchronize()
     chk(m._lib.svln_op_gemv(m._h, ptr(dWv), K, ptr(dx), None, 1e-6, None, None, None, V, K, _lib.EPI_ARGMAX, C.byref(tok)))
     assert tok.value == 77, tok.value
+    # non-finite logits (a NaN activation, or every logit -inf) must come back as -1 -- never as an out-of-range row index that
+    # the next step's embedding gather would dereference -- and finite maxima still win over NaN rows
+    xn = x.clone(); xn[3] = float("nan")
+    dxn = xn.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv(m._h, ptr(dWv), K, ptr(dxn), None, 1e-6, None, None, None, V, K, _lib.EPI_ARGMAX, C.byref(tok)))
+    assert tok.value == -1, tok.value
+    Wn = Wv.clone(); Wn[10:20] = float("nan")
+    dWn = Wn.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv(m._h, ptr(dWn), K, ptr(dx), None, 1e-6, None, None, None, V, K, _lib.EPI_ARGMAX, C.byref(tok)))
+    assert tok.value == 77, tok.value
+
+
+def test_forced_split_is_bounded_by_the_workspace():
+    """svln_op_gemm(force_split=S) must not write S fp32 slabs past the split-K workspace: rejected with an error"""
+    m = engine(TINY, torch.bfloat16)
+    M, N, K = 256, 4096, 512
+    A = torch.zeros((M, K), dtype=torch.bfloat16, device="cuda")
+    W = torch.zeros((N, K), dtype=torch.bfloat16, device="cuda")
+    Cm = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    rc = m._lib.svln_op_gemm(m._h, ptr(A), K, ptr(W), K, ptr(Cm), N, None, None, 0, 0, M, N, K, _lib.EPI_NONE, 0, 4096)
+    assert rc != 0 and b"workspace" in m._lib.svln_last_error()
+    rc = m._lib.svln_op_gemm(m._h, ptr(A), K, ptr(W), K, ptr(Cm), N - 2, None, None, 0, 0, M, N - 2, K, _lib.EPI_NONE, 0, 2)
+    assert rc != 0 and b"multiple of 4" in m._lib.svln_last_error()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,0 +1,138 @@
+"""Row a-1 (SigLipImageProcessor.preprocess, siglip_encoder.py:47-67): the integer restatement of Pillow's bicubic resize
+(oracle/pil_bicubic.py) against Pillow itself and against the reference-generated fixture (CPU), and the HIP kernel behind
+svln_preprocess_frames against all three, byte for byte (GPU)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import pil_bicubic as PB
+from oracle import streamvln_oracle as O
+from streamvln_amd.config import TINY
+from streamvln_amd.synthetic import synthetic_frame
+from util import load_golden
+
+
+def structured_frames():
+    """same generators as oracle/make_golden.py: smooth ramps, a saturated checkerboard, thin stripes (bicubic overshoot -> clip8)"""
+    y, x = np.mgrid[0:480, 0:640]
+    grad = np.stack([(x * 255 // 639), (y * 255 // 479), ((x + y) * 255 // 1118)], -1).astype(np.uint8)
+    checker = (((x // 3 + y // 5) % 2) * 255).astype(np.uint8)[..., None].repeat(3, -1)
+    stripes = np.stack([((x % 7) < 2) * 255, ((y % 4) < 1) * 255, ((x * y) % 256)], -1).astype(np.uint8)
+    return {"grad": grad, "checker": checker, "stripes": stripes}
+
+
+def fixture_frames():
+    frames = {f"synthetic_{s}": synthetic_frame(0, s) for s in range(4)}
+    frames.update(structured_frames())
+    return frames
+
+
+ODD_SIZES = [(384, 384), (100, 37), (720, 1280), (384, 640), (480, 384), (97, 1111), (1, 1), (2, 2), (1080, 1920), (33, 3000)]
+
+
+def pil_resize(frame, size=384):
+    return np.asarray(Image.fromarray(frame).resize((size, size), Image.BICUBIC))
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def check_against_fixture(key, chw_f32, g):
+    u8 = np.rint((chw_f32.astype(np.float64) * 0.5 + 0.5) * 255.0).astype(np.uint8)
+    assert np.array_equal(u8[:, 100, :], g[f"{key}_row100_u8"]), key
+    assert np.array_equal(u8.reshape(3, -1).astype(np.int64).sum(1), g[f"{key}_chan_sum_u8"]), key
+    assert np.array_equal(sha(u8), g[f"{key}_sha256_u8"]), key
+    assert np.array_equal(sha(chw_f32), g[f"{key}_sha256_f32"]), key
+
+
+# ------------------------------------------------------------------------------------------------- CPU: the oracle is pinned
+def test_restatement_equals_pillow_and_reference_fixture():
+    g = load_golden("preprocess")
+    for key, frame in fixture_frames().items():
+        mine = PB.resize_bicubic_u8(frame, 384, 384)
+        assert np.array_equal(mine, pil_resize(frame)), key
+        full = PB.siglip_preprocess(frame)
+        assert np.array_equal(full, O.siglip_preprocess(frame)), key
+        check_against_fixture(key, full, g)                      # whole-frame hashes through the reference's own SigLipImageProcessor
+
+
+@pytest.mark.parametrize("hw", ODD_SIZES)
+def test_restatement_equals_pillow_on_odd_geometries(hw):
+    rng = np.random.default_rng(hw[0] * 7919 + hw[1])
+    frame = rng.integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    assert np.array_equal(PB.resize_bicubic_u8(frame, 384, 384), pil_resize(frame))
+    assert np.array_equal(PB.resize_bicubic_u8(frame, 70, 70), pil_resize(frame, 70))       # other output sizes too
+
+
+def test_coefficient_tables_are_what_pillow_uses():
+    """640 -> 384: scale 5/3, support 10/3, 9 taps; rows sum to 2^22 within rounding; first/last windows are clipped"""
+    ks, xmin, cnt, kk = PB.precompute_coeffs(640, 384)
+    assert ks == 2 * 4 + 1 and xmin[0] == 0 and xmin[-1] + cnt[-1] == 640
+    assert np.abs(kk.sum(1) - (1 << 22)).max() <= ks and kk.min() < 0            # negative lobes exist
+    ks, xmin, cnt, kk = PB.precompute_coeffs(480, 384)
+    assert ks == 2 * 3 + 1 and cnt.max() <= ks
+    lut = PB.normalize_lut()
+    assert lut[0] == -1.0 and lut[255] == 1.0 and np.all(np.diff(lut) > 0)
+
+
+# ------------------------------------------------------------------------------------------------- GPU: the HIP kernel
+@pytest.fixture(scope="module")
+def model():
+    from streamvln_amd.model import StreamVLNForCausalLM
+    m = StreamVLNForCausalLM(TINY, dtype=torch.float32, max_envs=1, max_frames=1, max_positions=256)
+    yield m
+    m.close()
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_is_bit_exact_vs_pillow_oracle_and_fixture(model):
+    proc = model.get_vision_tower().image_processor
+    assert proc.backend == "hip"
+    g = load_golden("preprocess")
+    for key, frame in fixture_frames().items():
+        out = proc.preprocess_array(frame)
+        assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (3, 384, 384)
+        got = out.cpu().numpy()
+        assert np.array_equal(got, O.siglip_preprocess(frame)), key              # Pillow on this box
+        assert np.array_equal(got, PB.siglip_preprocess(frame)), key             # integer restatement
+        check_against_fixture(key, got, g)                                        # reference-generated hashes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", ODD_SIZES)
+def test_hip_preprocess_odd_geometries(model, hw):
+    rng = np.random.default_rng(hw[0] * 7919 + hw[1])
+    frame = rng.integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    proc = model.get_vision_tower().image_processor
+    got = proc.preprocess_array(frame).cpu().numpy()
+    assert np.array_equal(got, O.siglip_preprocess(frame)), hw
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_batch_pil_input_and_errors(model):
+    from streamvln_amd import _lib
+    proc = model.get_vision_tower().image_processor
+    frames = [synthetic_frame(1, s) for s in range(5)]
+    pv = proc.preprocess(images=[Image.fromarray(f) for f in frames], return_tensors="pt")["pixel_values"]     # one upload, one launch
+    assert pv.is_cuda and tuple(pv.shape) == (5, 3, 384, 384)
+    for f, got in zip(frames, pv.cpu().numpy()):
+        assert np.array_equal(got, O.siglip_preprocess(f))
+    one = proc.preprocess(images=Image.fromarray(frames[2]).convert("RGB"), return_tensors="pt")["pixel_values"][0]   # the reference call (streamvln_eval.py:271-274)
+    assert np.array_equal(one.cpu().numpy(), O.siglip_preprocess(frames[2]))
+    mixed = proc.preprocess(images=[frames[0], frames[1][:100, :200]], return_tensors="np")["pixel_values"]
+    assert np.array_equal(mixed[1], O.siglip_preprocess(frames[1][:100, :200]))
+    ms, n = model.preprocess_time(reset=True)
+    assert n >= 8 and ms > 0
+    with pytest.raises(ValueError):
+        proc.preprocess_array(np.zeros((10, 10), dtype=np.uint8))
+    with pytest.raises(_lib.SvlnError, match="100 x"):
+        proc.preprocess_array(np.zeros((3000, 5, 3), dtype=np.uint8))             # Pillow >= 12 goes vertical-first there
+    with pytest.raises(_lib.SvlnError, match="too large"):
+        proc.preprocess_array(np.zeros((2160, 3840, 3), dtype=np.uint8))
+    proc.backend = "pil"                                                          # explicit host path = Pillow itself
+    assert np.array_equal(proc.preprocess_array(frames[0]).numpy(), O.siglip_preprocess(frames[0]))
+    proc.backend = "hip"
