@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     using G = AttnGeom<T, 128>;
     constexpr int EPC = G::EPC, NT = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.skip && *p.skip) return;
     char* sK = smem;
     char* sV = smem + G::K_TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 template <typename T, int HD>
 __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
     __shared__ float wsh[64];
+    if (p.skip && *p.skip) return;
     const int rho = blockIdx.x, kh = blockIdx.y, env = blockIdx.z, lane = threadIdx.x;
     const int kv_len = p.slots ? p.slots[env].pos + 1 : (p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len);
     const int tiles = (kv_len + 63) >> 6;

@@ -136,7 +136,10 @@ public:
     float* inv_freq; float* rope_tab;
     float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
-    int* d_dyn;                  // [0] = position of the token being decoded, [1] = kv_len after it
+    GenCtl* d_ctl;               // device-side generation state (position / kv length of the next decode step, done flag, emitted count)
+    GenCtl* h_ctl = nullptr;     // pinned
+    int *d_eos = nullptr, *d_out_ids = nullptr, *h_out_ids = nullptr; std::vector<int> eos_cached; bool eos_valid = false;
+    static constexpr int RUN_AHEAD = 4;     // decode steps enqueued per host synchronisation (a typical turn: 4 action tokens + EOS)
     // batched (multi-env lockstep) decode
     static constexpr int MAXB = 8;
     static constexpr int batched_mfma_min = 4;    // measured at B = 8: 340 vs 319 action-steps/s (gate/up 58 vs 97 us per launch)
@@ -306,7 +309,11 @@ public:
             attn_part = dalloc<float>(attn_part_elems);
         }
         part_val = dalloc<float>(2048); part_idx = dalloc<int>(2048);
-        d_token = dalloc<int>(4, true); d_top2 = dalloc<float>(4, true); d_dyn = dalloc<int>(4, true);
+        d_token = dalloc<int>(4, true); d_top2 = dalloc<float>(4, true);
+        d_ctl = (GenCtl*)dalloc<int>(sizeof(GenCtl) / sizeof(int), true);
+        d_eos = dalloc<int>((size_t)(V > 16 ? V : 16)); d_out_ids = dalloc<int>((size_t)c.max_positions + 8);
+        HIP_CHECK(hipHostMalloc((void**)&h_ctl, sizeof(GenCtl)));
+        HIP_CHECK(hipHostMalloc((void**)&h_out_ids, ((size_t)c.max_positions + 8) * sizeof(int)));
         d_slots = dalloc<DecodeSlot>(MAXB, true); d_tok_b = dalloc<int>(MAXB, true);
         part_val_b = dalloc<float>((size_t)MAXB * 2048); part_idx_b = dalloc<int>((size_t)MAXB * 2048);
         last_rows = dalloc<T>((size_t)MAXB * H);
@@ -324,7 +331,6 @@ public:
         }
         for (int p = pages_total - 1; p >= 0; --p) free_pages.push_back(p);
         for (int i = 0; i < 5; ++i) HIP_CHECK(hipEventCreate(&ph_ev[i]));
-        HIP_CHECK(hipHostMalloc((void**)&h_dyn, 16));
         init_kernel_attributes();
         HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -338,9 +344,10 @@ public:
         if (d_rgb) (void)hipFree(d_rgb);
         if (h_rgb) (void)hipHostFree(h_rgb);
         for (int i = 0; i < 2; ++i) if (pp_ev[i]) (void)hipEventDestroy(pp_ev[i]);
+        if (src_ev) (void)hipEventDestroy(src_ev);
         for (auto e : probe_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
-        (void)hipHostFree(h_dyn);
+        (void)hipHostFree(h_ctl); (void)hipHostFree(h_out_ids);
         if (h_hash) (void)hipHostFree(h_hash);
         for (void* p : allocs) (void)hipFree(p);
         (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
@@ -628,8 +635,10 @@ public:
     }
 
     // ------------------------------------------------------------------------------- splice
+    hipEvent_t src_ev = nullptr; bool src_pending = false;      // h_src (pinned splice descriptor) is still being read by the last upload
     void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) override {
         Env& e = env_at(env);
+        if (src_pending) { HIP_CHECK(hipEventSynchronize(src_ev)); src_pending = false; }
         REQUIRE(frame_base >= 0 && n_memory >= 0 && frame_base + n_memory <= n_feat_frames, "n_memory exceeds encoded frames");
         int rows = 0, img = frame_base + n_memory, mem_used = 0;
         const int cap = c.max_positions - e.n_embeds;
@@ -660,7 +669,9 @@ public:
         }
         HIP_CHECK(hipMemcpyAsync(d_src, h_src, rows * sizeof(int), hipMemcpyHostToDevice, st));
         launch_gather_rows<T>(st, d_src, embed, feats, e.embeds + (size_t)e.n_embeds * H, rows, H);
-        HIP_CHECK(hipStreamSynchronize(st));         // h_src is reused by the next call
+        if (!src_ev) HIP_CHECK(hipEventCreateWithFlags(&src_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(src_ev, st));       // no stream synchronisation on the hot path: the next call waits for this upload only
+        src_pending = true;
         e.n_embeds += rows;
     }
 
@@ -672,8 +683,8 @@ public:
         a.n_kv_total = nkv; a.hpf = nkv; a.G = nq / nkv; a.T = Tn; a.P = P; a.kv_len = kv_len; a.scale = 1.0f / sqrtf(128.0f);
         a.part = attn_part; a.rows_pad = 32;
         if (decode) {
-            a.causal = 0; a.dyn_kv_len = d_dyn + 1; a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
-            a.fuse_rope_append = 1; a.rope_tab = rope_tab; a.dyn_pos = d_dyn; a.nq_heads = nq;
+            a.causal = 0; a.dyn_kv_len = &d_ctl->kv_len; a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split;
+            a.fuse_rope_append = 1; a.rope_tab = rope_tab; a.dyn_pos = &d_ctl->pos; a.nq_heads = nq; a.skip = &d_ctl->done;
         } else {
             a.causal = 1; a.dyn_kv_len = nullptr; a.nsplit = 1; a.tiles_per_split = pages_per_env;
             // few row blocks (steady turn: 12 x nkv workgroups): split the keys as well so the chip is filled
@@ -727,17 +738,24 @@ public:
     GemvArgs gemv_args(const void* W, int ldw, const void* xin, const void* norm_w, const void* bias, const void* res, void* y, int N, int K,
                        int epi) {
         GemvArgs a; a.W = W; a.ldw = ldw; a.x = xin; a.norm_w = norm_w; a.eps = c.rms_eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K;
-        a.epi = epi; a.part_val = part_val; a.part_idx = part_idx; a.w8 = nullptr; a.scale = nullptr; return a;
+        a.epi = epi; a.part_val = part_val; a.part_idx = part_idx; a.w8 = nullptr; a.scale = nullptr; a.skip = nullptr; return a;
     }
     GemvArgs with8(GemvArgs a, const Q8& q) { if (fp8_on) { a.w8 = q.q; a.scale = q.s; } return a; }
-    // final norm -> hidden tap row -> lm_head arg-max -> d_token  (lm_head on the LAST position only)
-    void head(const T* xrow, int tap_row) {
+    GemvArgs guarded(GemvArgs a) { a.skip = &d_ctl->done; return a; }      // decode-step launch: no-op once the generation is done
+    // final norm -> hidden tap row -> lm_head arg-max -> d_token  (lm_head on the LAST position only).
+    // `gen`: the arg-max also runs one step of the greedy loop on the device (GenCtl: append, EOS / max_new stop, advance the position)
+    // and every launch is guarded by the done flag.
+    void head(const T* xrow, int tap_row, bool gen) {
         T* tap = hid_tap + (size_t)(tap_row < HID_TAP_ROWS ? tap_row : HID_TAP_ROWS - 1) * H;
-        launch_rmsnorm<T>(st, xrow, final_norm, tap, 1, H, c.rms_eps);
-        launch_gemv<T>(st, with8(gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX), lm_head8));
-        launch_argmax_final(st, part_val, part_idx, gemv_grid(V), d_token, d_top2);
+        const int* skip = gen ? &d_ctl->done : nullptr;
+        launch_rmsnorm<T>(st, xrow, final_norm, tap, 1, H, c.rms_eps, skip);
+        GemvArgs a = with8(gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX), lm_head8);
+        a.skip = skip;
+        launch_gemv<T>(st, a);
+        if (gen) launch_argmax_step(st, part_val, part_idx, gemv_grid(V), d_token, d_top2, d_ctl, d_eos, d_out_ids);
+        else launch_argmax_final(st, part_val, part_idx, gemv_grid(V), d_token, d_top2);
     }
-    // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_dyn,
+    // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_ctl,
     // d_token) so any sub-range [lo, hi) of the sequence can be captured once and graph-replayed.
     // Op ids: 0 = embedding gather, then 6 per layer (qkv GEMV, attention with fused RoPE + KV append, combine, o GEMV,
     // gate/up GEMV, down GEMV); the layer-0 gate/up GEMV is op PROBE_OP.
@@ -747,29 +765,23 @@ public:
         const int qd = nq * 128;
         int op = 0;
         auto on = [&](void) { const bool r = op >= lo && op < hi; ++op; return r; };
-        if (on()) launch_gather_rows<T>(st, d_token, embed, feats, x, 1, H);
+        if (on()) launch_gather_rows<T>(st, d_token, embed, feats, x, 1, H, &d_ctl->done);
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
-            if (on()) launch_gemv<T>(st, with8(gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE), L.qkv8));
+            if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE), L.qkv8)));
             AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, 1, 0, 0, true);
             if (on()) launch_attention<T>(st, a, 128, 1);
             if (on()) launch_attention_combine<T>(st, a, 128);
-            if (on()) launch_gemv<T>(st, with8(gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE), L.o8));
-            if (on()) launch_gemv<T>(st, with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8));
-            if (on()) launch_gemv<T>(st, with8(gemv_args(L.down_w, I, hbuf, nullptr, nullptr, x, x, H, I, EPI_NONE), L.down8));
+            if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE), L.o8)));
+            if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8)));
+            if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.down_w, I, hbuf, nullptr, nullptr, x, x, H, I, EPI_NONE), L.down8)));
         }
-    }
-
-    int* h_dyn = nullptr;        // pinned
-    void set_dyn(int pos) {
-        h_dyn[0] = pos; h_dyn[1] = pos + 1;     // safe to overwrite: the previous step's copy completed before read_token returned
-        HIP_CHECK(hipMemcpyAsync(d_dyn, h_dyn, 2 * sizeof(int), hipMemcpyHostToDevice, st));
     }
 
     // layer-0 gate/up SwiGLU GEMV with the kernel's own begin/end timestamps
     void probe_launch(Env&) {
         const LLayer& L = ll[0];
-        launch_gemv_timed<T>(st, with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8), probe_ev[probe_used],
+        launch_gemv_timed<T>(st, guarded(with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8)), probe_ev[probe_used],
                              probe_ev[probe_used + 1]);
         probe_used += 2;
     }
@@ -788,9 +800,9 @@ public:
     }
     // HIP events bracket the layer-0 gate/up GEMV (launched directly between two captured halves) while probing;
     // that launch is the same kernel, grid and bytes as the other layers' gate/up GEMVs inside the graph.
+    // Enqueue one decode step (position, kv length and the fed token live in device memory: GenCtl / d_token); nothing here waits
+    // for the GPU, so several steps can be in flight behind one another.
     void decode_step(Env& e, int env, int tap_row) {
-        ensure_pages(e, e.kv_len + 1);           // the fed token sits at position kv_len
-        set_dyn(e.kv_len);
         const int n_ops = total_ops();
         const bool probing = probe_on && probe_used + 2 <= probe_ev.size();
         if (use_graph) {
@@ -815,8 +827,7 @@ public:
             probe_launch(e);
             decode_ops(e, PROBE_OP + 1, n_ops);
         }
-        head(x, tap_row);
-        e.kv_len += 1;
+        head(x, tap_row, true);
     }
 
     // ------------------------------------------------------------------------------- multi-env lockstep
@@ -847,7 +858,7 @@ public:
             if (mfma) launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE));
             else launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
             AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, qd, 1, 0, 0, true);
-            a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr;
+            a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr; a.skip = nullptr;
             a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * (128 + ATTN_PART_PAD);
             launch_attention<T>(st, a, 128, 1);
             launch_attention_combine<T>(st, a, 128);
@@ -984,40 +995,73 @@ public:
         return h_token[0];
     }
 
+    // StreamVLNForCausalLM.generate -> GenerationMixin._sample (greedy): prefill embeds[kv_len:], then feed each generated id until
+    // one is in the EOS set (appended, not fed) or max_new_tokens.  The loop state lives on the device (GenCtl): the prefill, its
+    // arg-max and RUN_AHEAD decode steps are enqueued back to back, then ONE synchronisation reads the ids emitted so far; steps
+    // enqueued past the end of the generation are no-ops (every kernel checks the done flag).
     void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) override {
         Env& e = env_at(env);
         REQUIRE(weights_missing() == 0, g_err);
         const int P = e.kv_len, L = e.n_embeds, Tn = L - P;
         REQUIRE(Tn >= 1, "nothing to prefill: inputs_embeds not longer than the KV cache");
         REQUIRE(max_new >= 1 && cap >= 1, "max_new_tokens must be >= 1");
+        if (fixed) n_eos = 0;
+        REQUIRE(n_eos >= 0 && n_eos <= (V > 16 ? V : 16), "too many eos ids");
+        const int limit = max_new < cap ? max_new : cap;                     // tokens this call may emit
+        {   // EOS set -> device (cached across calls: the harness passes the same list every turn)
+            std::vector<int> ev(n_eos);
+            for (int k = 0; k < n_eos; ++k) ev[k] = eos[k] >= 0 && eos[k] < V ? (int)eos[k] : -2;      // ids outside the vocabulary never match
+            if (!eos_valid || ev != eos_cached) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                eos_cached.swap(ev);
+                if (n_eos) HIP_CHECK(hipMemcpy(d_eos, eos_cached.data(), (size_t)n_eos * sizeof(int), hipMemcpyHostToDevice));
+                eos_valid = true;
+            }
+        }
         ensure_pages(e, L);
+        // the first decode step feeds token 0 at position L: pos / kv_len advance when the arg-max step appends without stopping
+        h_ctl->pos = L - 1; h_ctl->kv_len = L; h_ctl->done = 0; h_ctl->count = 0; h_ctl->max_new = limit; h_ctl->n_eos = n_eos;
+        h_ctl->pad0 = h_ctl->pad1 = 0;
+        HIP_CHECK(hipMemcpyAsync(d_ctl, h_ctl, sizeof(GenCtl), hipMemcpyHostToDevice, st));
         HIP_CHECK(hipEventRecord(ph_ev[2], st));
         prefill(e, P, Tn);
-        head(x + (size_t)(Tn - 1) * H, 0);
+        head(x + (size_t)(Tn - 1) * H, 0, true);
         e.kv_len = L;
         HIP_CHECK(hipEventRecord(ph_ev[3], st));
+        int enq = 1;                      // tokens whose arg-max step has been enqueued
         int n = 0;
+        bool done = false, decoded = false;
         while (true) {
-            const int tok = read_token();       // synchronises the stream
-            REQUIRE(tok >= 0 && tok < V, "non-finite logits: the arg-max found no finite value (check the weights / fp8 scales)");
-            if (n == 0) {
-                float t = 0.f;
-                HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[1] += t;
-                if (vision_pending) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
+            int steps = limit - enq;
+            if (steps > RUN_AHEAD) steps = RUN_AHEAD;
+            if (steps > c.max_positions - (L + enq - 1)) steps = c.max_positions - (L + enq - 1);       // step k feeds position L + enq - 1
+            for (int k = 0; k < steps; ++k) {
+                ensure_pages(e, L + enq);
+                decode_step(e, env, enq);
+                ++enq;
+                decoded = true;
             }
-            if (n < cap) out[n] = tok;
-            ++n;
-            bool stop = n >= max_new || n >= cap;
-            if (!fixed) for (int k = 0; k < n_eos; ++k) if (eos[k] == tok) stop = true;
-            if (stop) break;
-            REQUIRE(e.kv_len + 1 <= c.max_positions, "sequence exceeds max_positions during decode");
-            decode_step(e, env, n);
+            if (decoded) HIP_CHECK(hipEventRecord(ph_ev[4], st));
+            HIP_CHECK(hipMemcpyAsync(h_ctl, d_ctl, sizeof(GenCtl), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(h_out_ids, d_out_ids, (size_t)enq * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(h_top2, d_top2, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            LAUNCH_CHECK("generate");
+            n = h_ctl->count;
+            done = h_ctl->done != 0;
+            REQUIRE(n >= 1 && n <= enq, "generation state out of range");
+            for (int k = 0; k < n; ++k)
+                REQUIRE(h_out_ids[k] >= 0 && h_out_ids[k] < V, "non-finite logits: the arg-max found no finite value (check the weights / fp8 scales)");
+            if (done) break;
+            REQUIRE(steps > 0, "sequence exceeds max_positions during decode");
         }
-        if (n > 1) {
+        for (int k = 0; k < n; ++k) out[k] = h_out_ids[k];
+        e.kv_len = L + n - 1;             // EOS (or the last token) is appended to the ids but never fed
+        {
             float t = 0.f;
-            HIP_CHECK(hipEventRecord(ph_ev[4], st));
-            HIP_CHECK(hipEventSynchronize(ph_ev[4]));
-            HIP_CHECK(hipEventElapsedTime(&t, ph_ev[3], ph_ev[4])); ph_ms[2] += t;
+            HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[1] += t;
+            if (vision_pending) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
+            if (decoded) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[3], ph_ev[4])); ph_ms[2] += t; }
         }
         n_generated = n;
         *n_out = n;
@@ -1290,7 +1334,7 @@ int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const vo
                  int N, int K, int epi, int32_t* host_token) {
     API_BEGIN_H
     GemvArgs a; a.W = W; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
-    a.part_val = nullptr; a.part_idx = nullptr; a.w8 = nullptr; a.scale = nullptr;
+    a.part_val = nullptr; a.part_idx = nullptr; a.w8 = nullptr; a.scale = nullptr; a.skip = nullptr;
     h->impl->op_gemv(a, host_token);
     API_END
 }
@@ -1302,7 +1346,7 @@ int svln_op_gemv_fp8(svln_engine* h, const void* w8, const float* scale, int ldw
     API_BEGIN_H
     if (K % 16 != 0) throw std::runtime_error("K must be a multiple of 16");
     GemvArgs a; a.W = nullptr; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
-    a.part_val = nullptr; a.part_idx = nullptr; a.w8 = w8; a.scale = scale;
+    a.part_val = nullptr; a.part_idx = nullptr; a.w8 = w8; a.scale = scale; a.skip = nullptr;
     h->impl->op_gemv(a, host_token);
     API_END
 }

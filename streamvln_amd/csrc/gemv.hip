@@ -136,6 +136,7 @@ template <typename T, bool NORM, int R>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_ksplit_kernel(GemvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ float part[GEMV_WAVES][R + 1];
+    if (p.skip && *p.skip) return;
     constexpr int EPC = Elt<T>::PER_CHUNK;
     const int nch = p.K / EPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -359,6 +360,7 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* xs = (float*)smem_raw;
+    const int skip = p.skip ? *p.skip : 0;        // checked after the activation staging, so the flag's load latency hides behind it
     constexpr int EPC = Elt<T>::PER_CHUNK;
     constexpr int R = 4;
     const int nch = p.K / EPC;
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
             }
         };
         const float xscale = stage_x<T>(xs, p, nch);
+        if (skip) return;
         auto finish = [&](int j0, const float (&acc)[R]) {
             if (lane < 2 && j0 + lane < n_out) {
                 const float gt = (lane == 0 ? acc[0] : acc[2]) * xscale, up = (lane == 0 ? acc[1] : acc[3]) * xscale;
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
         return;
     }
     const float xscale = stage_x<T>(xs, p, nch);
+    if (skip) return;
 
     float best = -INFINITY;
     int best_i = 0x7FFFFFFF;
@@ -539,9 +543,11 @@ template <int EPI>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv8_kernel(GemvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* xs = (float*)smem_raw;
+    const int skip = p.skip ? *p.skip : 0;
     constexpr int R = 4;
     const int nch8 = p.K / 16;
     const float xscale = stage_x8(xs, p, nch8);
+    if (skip) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * GEMV_WAVES + wave, nw = gridDim.x * GEMV_WAVES;
     const uint8_t* W = (const uint8_t*)p.w8;
@@ -610,6 +616,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv8_kernel(GemvArgs p) {
 template <bool NORM, int R>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv8_ksplit_kernel(GemvArgs p) {
     __shared__ float part[GEMV_WAVES][R + 1];
+    if (p.skip && *p.skip) return;
     const int nch8 = p.K / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t* W = (const uint8_t*)p.w8;
@@ -700,8 +707,11 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* w, int 
 }
 
 // final arg-max over per-workgroup partials: greatest value, lowest index on ties (torch.argmax on CPU)
-__global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, const int* pi, int n, int* out_token, float* out_top) {
+// With `ctl` it is also one step of the greedy loop (GenerationMixin._sample: append, stop on EOS / max_new_tokens): see GenCtl.
+__global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, const int* pi, int n, int* out_token, float* out_top, GenCtl* ctl,
+                                                           const int* eos, int* out_ids) {
     __shared__ float sv[256];
+    if (ctl && ctl->done) return;
     __shared__ int si[256];
     __shared__ float s2[256];
     float v = -INFINITY, v2 = -INFINITY;
@@ -723,10 +733,23 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, cons
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        *out_token = si[0] == 0x7FFFFFFF ? -1 : si[0];     // no finite logit (NaN / -inf everywhere): -1, which the next embedding gather
+    const int tok = si[0] == 0x7FFFFFFF ? -1 : si[0];      // no finite logit (NaN / -inf everywhere): -1, which the next embedding gather
                                                            // reads as frame-feature row 0 (in range) and the host reports as an error
+    if (threadIdx.x == 0) {
+        *out_token = tok;
         if (out_top) { out_top[0] = sv[0]; out_top[1] = s2[0]; }
+    }
+    if (ctl) {
+        int hit = 0;
+        for (int k = threadIdx.x; k < ctl->n_eos; k += 256) hit |= eos[k] == tok;
+        hit = __syncthreads_or(hit);
+        if (threadIdx.x == 0) {
+            const int c = ctl->count;
+            out_ids[c] = tok;
+            ctl->count = c + 1;
+            if (hit || tok < 0 || c + 1 >= ctl->max_new) ctl->done = 1;      // EOS is appended, never fed
+            else { ctl->pos += 1; ctl->kv_len += 1; }
+        }
     }
 }
 
@@ -844,7 +867,11 @@ template void launch_gemv<bf16>(hipStream_t, const GemvArgs&);
 template void launch_gemv<float>(hipStream_t, const GemvArgs&);
 
 void launch_argmax_final(hipStream_t s, const float* pv, const int* pi, int n, int* out_token, float* out_top) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top, (GenCtl*)nullptr, (const int*)nullptr, (int*)nullptr);
+}
+void launch_argmax_step(hipStream_t s, const float* pv, const int* pi, int n, int* out_token, float* out_top, GenCtl* ctl, const int* eos,
+                        int* out_ids) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top, ctl, eos, out_ids);
 }
 
 }  // namespace svln

@@ -50,6 +50,7 @@ struct GemvArgs {
     // optional fp8 (OCP e4m3) weight-only path (bf16 engine, opt-in): w8 [N][K] bytes, one fp32 scale per row,
     // W[n][k] ~= scale[n] * e4m3(w8[n][k]); when set, W is ignored
     const void* w8; const float* scale;
+    const int* skip;              // optional device flag: the launch is a no-op when *skip != 0 (generation finished: run-ahead decode steps)
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 // per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 16 == 0): scale[r] = max|W[r]| / 448
@@ -74,6 +75,19 @@ int gemv_batched_grid(int N, int epi, int B);
 void launch_argmax_final_batched(hipStream_t s, const float* part_val, const int* part_idx, int n, int B, int* out_tokens);
 void launch_argmax_final(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token,
                          float* out_top /*[2]: best, runner-up of partial maxima (diagnostic)*/);
+// Device-side state of one greedy generation (GenerationMixin._sample: append the arg-max, stop on EOS or max_new_tokens), so that
+// decode steps can be enqueued ahead of the host: every kernel of a step is a no-op once `done` is set.
+struct GenCtl {
+    int pos;        // position of the token the next decode step feeds (read by the attention kernel: RoPE, KV append)
+    int kv_len;     // keys visible to that step (= pos + 1)
+    int done;       // set by the arg-max step that emitted EOS / the max_new-th token / a non-finite arg-max (-1)
+    int count;      // tokens emitted so far (out_ids[0 .. count))
+    int max_new, n_eos, pad0, pad1;
+};
+// launch_argmax_final + the bookkeeping above: out_ids[count++] = token; done |= token in eos[0 .. n_eos) || count == max_new || token < 0;
+// otherwise pos / kv_len advance by one.  No-op when ctl->done is already set.
+void launch_argmax_step(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token, float* out_top, GenCtl* ctl,
+                        const int* eos, int* out_ids);
 
 // Flash-style attention over paged K / V^T tiles (64 keys per page).
 //   pools:  K  [page][n_kv_total][64][HDP]        HDP = head dim padded to an even chunk count
@@ -110,12 +124,13 @@ struct AttnArgs {
     const DecodeSlot* slots;
     size_t part_bstride;
     int batch;
+    const int* skip;              // optional device flag: decode attention / combine are no-ops when *skip != 0
 };
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves);
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);
 
 // RMSNorm / LayerNorm over rows of length n (T in, T out).
-template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps);
+template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip = nullptr);
 template <typename T> void launch_layernorm(hipStream_t s, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps);
 
 // RoPE on q,k (in place on q) + append roped k and v to the paged cache.
@@ -150,7 +165,7 @@ template <typename T> void launch_pool(hipStream_t s, const void* in, void* out,
 template <typename T> void launch_memory_prune(hipStream_t s, const void* m, int n_rows, int H, int keep, float* partial, float* mean, float* score,
                                                int* sel);
 template <typename T> void launch_gather_rows(hipStream_t s, const int* src, const void* embed, const void* feats, void* out,
-                                              int rows, int n);
+                                              int rows, int n, const int* skip = nullptr);
 
 // weights: synthesize (see weights.py) or convert canonical rows into packed rows
 // dst row = (r / blk) * blk * nint + phase * blk + r % blk ; cols copied to [0, cols), dst_ld >= cols

@@ -12,8 +12,9 @@ namespace {
 // ------------------------------------------------------------------------------------------ norms
 // one wave per row; three cached passes (the row stays in L1/L2): statistics in fp32.
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* g, T* y, int rows, int n, float eps) {
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* g, T* y, int rows, int n, float eps, const int* skip) {
     constexpr int EPC = Elt<T>::PER_CHUNK;
+    if (skip && *skip) return;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -213,8 +214,9 @@ __global__ __launch_bounds__(256) void pool_kernel(const T* in, T* out, const in
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gather_rows_kernel(const int* src, const T* embed, const T* feats, T* out, int n) {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int* src, const T* embed, const T* feats, T* out, int n, const int* skip) {
     constexpr int EPC = Elt<T>::PER_CHUNK;
+    if (skip && *skip) return;
     const int row = blockIdx.x;
     const int sidx = src[row];
     const T* s = sidx >= 0 ? embed + (size_t)sidx * n : feats + (size_t)(-(sidx + 1)) * n;
@@ -322,9 +324,9 @@ int grid_for(int64_t n) {
 
 }  // namespace
 
-template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps) {
+template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (T*)y, rows, n, eps);
+    hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (T*)y, rows, n, eps, skip);
 }
 template <typename T> void launch_layernorm(hipStream_t s, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) {
     if (rows <= 0) return;
@@ -356,9 +358,10 @@ template <typename T> void launch_pool(hipStream_t s, const void* in, void* out,
                                        int out_side, int C) {
     hipLaunchKernelGGL((pool_kernel<T>), dim3(F * out_side * out_side), dim3(256), 0, s, (const T*)in, (T*)out, tap_idx, tap_w, side, out_side, C);
 }
-template <typename T> void launch_gather_rows(hipStream_t s, const int* src, const void* embed, const void* feats, void* out, int rows, int n) {
+template <typename T> void launch_gather_rows(hipStream_t s, const int* src, const void* embed, const void* feats, void* out, int rows, int n,
+                                              const int* skip) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(rows), dim3(256), 0, s, src, (const T*)embed, (const T*)feats, (T*)out, n);
+    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(rows), dim3(256), 0, s, src, (const T*)embed, (const T*)feats, (T*)out, n, skip);
 }
 // scratch: partial [ceil(n/64)][H] floats, mean [H], score [n]; sel [keep] ints (ascending row indices)
 template <typename T> void launch_memory_prune(hipStream_t s, const void* m, int n_rows, int H, int keep, float* partial, float* mean, float* score,
@@ -387,13 +390,13 @@ template <typename T> void launch_from_f32(hipStream_t s, const float* src, void
 }
 
 #define SVLN_INST(T)                                                                                                              \
-    template void launch_rmsnorm<T>(hipStream_t, const void*, const void*, void*, int, int, float);                              \
+    template void launch_rmsnorm<T>(hipStream_t, const void*, const void*, void*, int, int, float, const int*);                              \
     template void launch_layernorm<T>(hipStream_t, const void*, const void*, const void*, void*, int, int, float);               \
     template void launch_rope_kv<T>(hipStream_t, const RopeKvArgs&);                                                              \
     template void launch_vit_kv_pack<T>(hipStream_t, const void*, int, void*, void*, int, int, int, int);                         \
     template void launch_patchify<T>(hipStream_t, const float*, void*, int, int, int, int);                                       \
     template void launch_pool<T>(hipStream_t, const void*, void*, const int*, const float*, int, int, int, int);                  \
-    template void launch_gather_rows<T>(hipStream_t, const int*, const void*, const void*, void*, int, int);                      \
+    template void launch_gather_rows<T>(hipStream_t, const int*, const void*, const void*, void*, int, int, const int*);                      \
     template void launch_memory_prune<T>(hipStream_t, const void*, int, int, int, float*, float*, float*, int*);                   \
     template void launch_synth<T>(hipStream_t, void*, int, int64_t, int, RowMap, uint64_t, float, float);                          \
     template void launch_convert<T>(hipStream_t, void*, int, int64_t, int, RowMap, const void*, int);                              \
