@@ -87,6 +87,16 @@ int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out_ids)
 int svln_append_turn_at(svln_engine* h, int env, const int64_t* ids, int n_ids, int frame_base, int n_memory);
 int svln_generate_batch(svln_engine* h, const int32_t* envs, int n_envs, int max_new_tokens, const int64_t* eos_ids, int n_eos,
                         int64_t* out_ids, int out_cap, int32_t* n_out);
+/* -- the scheduler underneath svln_generate_batch, for callers whose envs' turns fall due at DIFFERENT times (a DAgger-style
+ * collector mixing expert and model steps per env, streamvln_dagger.py:232-313): iteration-level batching.
+ * svln_batch_submit: the env (turn already appended with svln_append_turn[_at]) joins the next iteration; *slot identifies the turn.
+ * svln_batch_step: ONE pass over the weights carrying, for every turn in flight, either its prefill rows or the row of the token it
+ * generated in the previous iteration (prefilling and decoding envs share the pass); *running = turns still in flight afterwards,
+ * finished_slots[0 .. *n_finished) = turns that emitted EOS / max_new_tokens in this iteration (<= 8 entries).
+ * svln_batch_result: ids of a finished turn (frees the slot).  Per-env results are exactly those of svln_generate. */
+int svln_batch_submit(svln_engine* h, int env, int max_new_tokens, const int64_t* eos_ids, int n_eos, int32_t* slot);
+int svln_batch_step(svln_engine* h, int32_t* running, int32_t* finished_slots, int32_t* n_finished);
+int svln_batch_result(svln_engine* h, int slot, int32_t* env, int64_t* out_ids, int out_cap, int32_t* n_out);
 int svln_get_hidden_batch(svln_engine* h, int slot, float* host_out, int max_rows, int32_t* n_rows);   /* parity tap, <= 8 rows */
 
 /* -- parity taps (test infrastructure reads these; not used by the product path) */
@@ -130,6 +140,10 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
+/* B (1, 2, 4 or 8) activation vectors x [B][ldx] against one weight stream (the decode step of svln_generate_batch / svln_batch_step at
+ * B <= 2, and its lm_head at every B): y [B][ldy], res [B][ldr]; EPI_ARGMAX writes one token per vector to host_tokens[B] */
+int svln_op_gemv_batched(svln_engine* h, const void* W, int ldw, const void* x, int ldx, const void* norm_w, float eps, const void* bias,
+                         const void* res, int ldr, void* y, int ldy, int N, int K, int epi, int B, int32_t* host_tokens);
 /* the selection step of svln_set_memory_prune on mem [n_rows][hidden] (engine dtype, device): out_idx[keep] ascending row indices
  * (host), out_score [n_rows] cosine scores (host, optional) */
 int svln_op_memory_prune(svln_engine* h, const void* mem, int n_rows, int keep, int32_t* out_idx, float* out_score);

@@ -47,6 +47,9 @@ SIGNATURES = {
     "svln_append_turn": (_I, [_P, _I, _PI64, _I, _I]),
     "svln_append_turn_at": (_I, [_P, _I, _PI64, _I, _I, _I]),
     "svln_generate_batch": (_I, [_P, _PI32, _I, _I, _PI64, _I, _PI64, _I, _PI32]),
+    "svln_batch_submit": (_I, [_P, _I, _I, _PI64, _I, _PI32]),
+    "svln_batch_step": (_I, [_P, _PI32, _PI32, _PI32]),
+    "svln_batch_result": (_I, [_P, _I, _PI32, _PI64, _I, _PI32]),
     "svln_get_hidden_batch": (_I, [_P, _I, _PF, _I, _PI32]),
     "svln_generate": (_I, [_P, _I, _I, _PI64, _I, _PI64, _I, _PI32]),
     "svln_generate_fixed": (_I, [_P, _I, _I, _PI64]),
@@ -66,6 +69,7 @@ SIGNATURES = {
     "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemm_norm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _PI32]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
+    "svln_op_gemv_batched": (_I, [_P, _P, _I, _P, _I, _P, _F, _P, _P, _I, _P, _I, _I, _I, _I, _I, _PI32]),
     "svln_op_quant_fp8": (_I, [_P, _P, _I64, _I, _P, _P]),
     "svln_op_gemv_fp8": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
     "svln_op_rmsnorm": (_I, [_P, _P, _P, _P, _I, _I, _F]),

@@ -63,6 +63,7 @@ class StreamingAgent:
             preprocess = lambda rgb: proc.preprocess_array(rgb)
         self.preprocess = preprocess
         self.turn_log: List[dict] = []
+        self.pending_turn = False          # AsyncBatchedAgents: the model turn of the current env step has returned, the step itself is pending
         self.reset_memory()
 
     def reset_memory(self):                                   # streamvln_agent.py:87-99
@@ -174,3 +175,52 @@ class BatchedAgents:
             for a, out in zip(due, outs):
                 a.action_seq = a._consume(out)
         return [a.finish_step() for a in self.agents]
+
+
+class AsyncBatchedAgents:
+    """Several envs on one GPU whose model turns fall due at DIFFERENT times (the DAgger collector's situation: each env mixes
+    expert steps, which need no model call, with model steps; streamvln_dagger.py:232-313).  `tick(rgbs)` advances every env that
+    is not waiting for the model by one env step (an env whose action queue is empty submits its turn instead) and then runs ONE
+    scheduler iteration (`model.step_batch`): envs that submitted in earlier ticks are decoding while new ones prefill, all in the
+    same pass over the weights.  Returns {agent index: action taken} for the envs that stepped in this tick."""
+
+    def __init__(self, agents, on_result=None):
+        self.agents = list(agents)
+        self.model = self.agents[0].model
+        self.waiting = {}                                 # scheduler slot -> agent index
+        self.on_result = on_result                        # optional callback(agent index, ticket, GenerateOutput)
+        self.stats = {"iterations": 0, "mixed_iterations": 0, "max_in_flight": 0}
+
+    def tick(self, rgbs, instructions=None, active=None):
+        """`rgbs[i]`: the frame of agent i's current env step (ignored for agents that are waiting); `active`: indices allowed to
+        step in this tick (default: all)."""
+        instructions = instructions or [""] * len(self.agents)
+        acted = {}
+        busy = set(self.waiting.values())
+        for i, a in enumerate(self.agents):
+            if i in busy or (active is not None and i not in active):
+                continue
+            if a.pending_turn:                            # its turn came back in an earlier tick: take the env step now
+                a.pending_turn = False
+                acted[i] = a.finish_step()
+                continue
+            if a.observe(rgbs[i]):
+                t = self.model.submit(**a._build_request(instructions[i]))
+                self.waiting[t.slot] = i
+            else:
+                acted[i] = a.finish_step()
+        if not self.waiting:
+            return acted
+        n_new = len(self.waiting) - len(busy)
+        self.stats["iterations"] += 1
+        self.stats["mixed_iterations"] += int(n_new > 0 and len(busy) > 0)      # new turns prefill while older ones decode
+        self.stats["max_in_flight"] = max(self.stats["max_in_flight"], len(self.waiting))
+        done, _ = self.model.step_batch()
+        for ticket, out in done:
+            i = self.waiting.pop(ticket.slot)
+            a = self.agents[i]
+            a.action_seq = a._consume(out)
+            a.pending_turn = True
+            if self.on_result is not None:
+                self.on_result(i, ticket, out)
+        return acted

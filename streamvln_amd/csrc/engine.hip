@@ -77,6 +77,9 @@ struct EngineBase {
     virtual void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) = 0;
     virtual void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) = 0;
     virtual void generate_batch(const int32_t* envs, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) = 0;
+    virtual int batch_submit(int env, int max_new, const int64_t* eos, int n_eos) = 0;
+    virtual int batch_step(int32_t* finished_slots, int32_t* n_finished) = 0;
+    virtual void batch_result(int slot, int32_t* env, int64_t* out, int cap, int32_t* n_out) = 0;
     virtual void get_hidden_batch(int slot, float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_hidden(float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_embeds(int env, int start, int n, float* out) = 0;
@@ -94,6 +97,7 @@ struct EngineBase {
     virtual void feature_cache_stats(int64_t* hits, int64_t* misses) = 0;
     virtual bool op_gemm(const GemmArgs& a) = 0;
     virtual void op_gemv(GemvArgs a, int32_t* host_token) = 0;
+    virtual void op_gemv_batched(GemvBatchArgs a, int32_t* host_tokens) = 0;
     virtual void op_quant_fp8(const void* w, int64_t rows, int cols, void* w8, float* scale) = 0;
     virtual void op_rmsnorm(const void* x, const void* g, void* y, int rows, int n, float eps) = 0;
     virtual void op_layernorm(const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) = 0;
@@ -702,7 +706,10 @@ public:
     struct Seg { Env* e; int P, Tn, off; };       // rows [off, off + Tn) of the prefill batch belong to env e at positions P..
     // Qwen2DecoderLayer stack (modeling_qwen2.py:269-299) over the concatenated new rows of one or several envs:
     // the dense products run once on all rows; RoPE + KV append and attention run per env (own pages / positions).
-    void prefill_rows(const std::vector<Seg>& segs, int M) {
+    // n_dec > 0 (mixed iteration of the multi-env scheduler): rows [0, n_dec) are single-token decode rows of n_dec other envs
+    // (x already holds their token embeddings, d_slots their page tables / positions); they share every dense product with the
+    // prefill rows and run the batched decode attention (fused RoPE + KV append) instead of the per-segment prefill attention.
+    void prefill_rows(const std::vector<Seg>& segs, int M, int n_dec = 0) {
         const int qd = nq * 128;
         for (const Seg& g : segs)
             HIP_CHECK(hipMemcpyAsync(x + (size_t)g.off * H, g.e->embeds + (size_t)g.P * H, (size_t)g.Tn * H * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -711,6 +718,11 @@ public:
             const LLayer& L = ll[i];
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
             launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE));
+            if (n_dec > 0) {
+                AttnArgs a = batched_decode_attn_args(L, n_dec);
+                launch_attention<T>(st, a, 128, 1);
+                launch_attention_combine<T>(st, a, 128);
+            }
             for (const Seg& g : segs) {
                 T* q_g = qkv + (size_t)g.off * qkv_dim;
                 RopeKvArgs r; r.qkv = q_g; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = g.e->d_pages; r.rope_tab = rope_tab;
@@ -729,6 +741,12 @@ public:
             if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
             xn_ready = launch_gemm<T>(st, ad);
         }
+    }
+    AttnArgs batched_decode_attn_args(const LLayer& L, int B) {
+        AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, nq * 128, 1, 0, 0, true);
+        a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr; a.skip = nullptr;
+        a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * (128 + ATTN_PART_PAD);
+        return a;
     }
     void prefill(Env& e, int P, int Tn) {
         std::vector<Seg> segs{Seg{&e, P, Tn, 0}};
@@ -857,9 +875,7 @@ public:
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, B, H, c.rms_eps);
             if (mfma) launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE));
             else launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
-            AttnArgs a = llm_attn_args(L, envs[0], qkv, qkv_dim, attn, qd, 1, 0, 0, true);
-            a.page_table = nullptr; a.dyn_kv_len = nullptr; a.dyn_pos = nullptr; a.skip = nullptr;
-            a.slots = d_slots; a.batch = B; a.part_bstride = (size_t)nsplit_max * nkv * 32 * (128 + ATTN_PART_PAD);
+            AttnArgs a = batched_decode_attn_args(L, B);
             launch_attention<T>(st, a, 128, 1);
             launch_attention_combine<T>(st, a, 128);
             if (mfma) {
@@ -886,99 +902,158 @@ public:
         HIP_CHECK(hipMemcpyAsync(hid_tap + (size_t)(t * MAXB + slot) * H, row, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
     }
 
-    // Equivalent to svln_generate on each env in turn (per-env semantics = the batch-1 path), executed in lockstep:
-    // prefill rows of all envs through the dense layers together, then decode steps for the still-active envs at once.
-    void generate_batch(const int32_t* env_ids, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap,
-                        int32_t* n_out) override {
-        REQUIRE(n_envs >= 1 && n_envs <= MAXB, "1..8 envs per batch");
+    // ---- multi-env scheduler (caller = a DAgger-style collector whose envs mix expert and model steps, so their model
+    // turns fall due at different times: streamvln_dagger.py:232-313).  Per-env semantics are those of svln_generate; execution is
+    // iteration-level batching: every iteration is ONE pass over the weights that carries, for each active env, either the rows of
+    // its new turn (prefill) or the single row of the token it generated in the previous iteration (decode).  Envs join at any
+    // iteration (svln_batch_submit) and leave when they emit EOS / max_new_tokens, so prefilling and decoding envs share passes.
+    struct Job {
+        bool used = false, finished = false, prefill = true;
+        int env = -1, max_new = 0, count = 0, last_tok = -1;
+        std::vector<int64_t> out, eos;
+    };
+    Job jobs[MAXB];
+    int batch_submit(int env, int max_new, const int64_t* eos, int n_eos) override {
+        Env& e = env_at(env);
         REQUIRE(weights_missing() == 0, g_err);
-        REQUIRE(max_new >= 1 && cap >= 1, "max_new_tokens must be >= 1");
-        std::vector<Env*> es(n_envs);
-        for (int s = 0; s < n_envs; ++s) {
-            es[s] = &env_at(env_ids[s]);
-            for (int t = 0; t < s; ++t) REQUIRE(env_ids[t] != env_ids[s], "duplicate env in batch");
-            REQUIRE(es[s]->n_embeds - es[s]->kv_len >= 1, "nothing to prefill for an env of the batch");
+        REQUIRE(max_new >= 1, "max_new_tokens must be >= 1");
+        REQUIRE(e.n_embeds - e.kv_len >= 1, "nothing to prefill for this env (append its turn first)");
+        int slot = -1;
+        for (int k = 0; k < MAXB; ++k) {
+            REQUIRE(!(jobs[k].used && jobs[k].env == env), "this env already has a turn in flight");
+            if (slot < 0 && !jobs[k].used) slot = k;
+        }
+        REQUIRE(slot >= 0, "at most 8 turns in flight");
+        Job& j = jobs[slot];
+        j = Job();
+        j.used = true; j.env = env; j.max_new = max_new < c.max_positions ? max_new : c.max_positions;
+        j.eos.assign(eos, eos + n_eos);
+        n_generated_b[slot] = 0;
+        return slot;
+    }
+    // one iteration; returns the number of jobs still running afterwards, finished_slots = jobs that completed in this iteration
+    int batch_step(int32_t* finished_slots, int32_t* n_finished) override {
+        *n_finished = 0;
+        std::vector<int> dec, pre;                      // job slots decoding / prefilling in this iteration
+        for (int k = 0; k < MAXB; ++k)
+            if (jobs[k].used && !jobs[k].finished) (jobs[k].prefill ? pre : dec).push_back(k);
+        if (dec.empty() && pre.empty()) return 0;
+        const int nd = (int)dec.size();
+        // prefill jobs that fit the row workspaces next to the decode rows (the rest wait for the next iteration)
+        std::vector<Seg> segs;
+        std::vector<int> pre_now;
+        int M = nd;
+        for (int k : pre) {
+            Env& e = envs[jobs[k].env];
+            const int Tn = e.n_embeds - e.kv_len;
+            REQUIRE(Tn <= c.max_positions - MAXB, "prefill longer than the row workspace");
+            if (!segs.empty() && M + Tn > c.max_positions) continue;
+            ensure_pages(e, e.n_embeds);
+            segs.push_back(Seg{&e, e.kv_len, Tn, M});
+            pre_now.push_back(k);
+            M += Tn;
         }
         HIP_CHECK(hipEventRecord(ph_ev[2], st));
-        // ---- prefill in groups whose rows fit the workspaces
-        int s0 = 0;
-        while (s0 < n_envs) {
-            std::vector<Seg> segs;
-            int M = 0, s1 = s0;
-            while (s1 < n_envs) {
-                Env& e = *es[s1];
-                const int Tn = e.n_embeds - e.kv_len;
-                if (!segs.empty() && M + Tn > c.max_positions) break;
-                REQUIRE(Tn <= c.max_positions, "prefill longer than max_positions");
-                ensure_pages(e, e.n_embeds);
-                segs.push_back(Seg{&e, e.kv_len, Tn, M});
-                M += Tn;
-                ++s1;
-            }
-            prefill_rows(segs, M);
-            for (size_t k = 0; k < segs.size(); ++k) {
-                const T* last = x + (size_t)(segs[k].off + segs[k].Tn - 1) * H;
-                HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)(s0 + k) * H, last, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
-                segs[k].e->kv_len = segs[k].e->n_embeds;
-            }
-            s0 = s1;
-        }
-        int Bp = 1; while (Bp < n_envs) Bp <<= 1;
-        for (int s = n_envs; s < Bp; ++s)            // pad to a power of two with copies of env slot 0 (results ignored)
-            HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)s * H, last_rows, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
-        head_batched(last_rows, Bp);
-        for (int s = 0; s < n_envs; ++s) tap_copy(xn + (size_t)s * H, 0, s);
-        HIP_CHECK(hipEventRecord(ph_ev[3], st));
-
-        std::vector<int> active(n_envs), count(n_envs, 0);
-        for (int s = 0; s < n_envs; ++s) active[s] = s;
-        bool first = true;
-        while (true) {
-            const int Bn = (int)active.size();
-            int Bq = 1; while (Bq < Bn) Bq <<= 1;
-            HIP_CHECK(hipMemcpyAsync(h_tok_b, d_tok_b, Bq * sizeof(int), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (first) {
-                float t = 0.f;
-                HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[1] += t;
-                if (vision_pending) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
-                first = false;
-            }
-            std::vector<int> next; std::vector<int> next_tok;
-            for (int k = 0; k < Bn; ++k) {
-                const int s = active[k], tok = h_tok_b[k];
-                REQUIRE(tok >= 0 && tok < V, "non-finite logits: the arg-max found no finite value (check the weights / fp8 scales)");
-                if (count[s] < cap) out[(size_t)s * cap + count[s]] = tok;
-                ++count[s];
-                bool stop = count[s] >= max_new || count[s] >= cap;
-                for (int q = 0; q < n_eos; ++q) if (eos[q] == tok) stop = true;
-                if (!stop) { next.push_back(s); next_tok.push_back(tok); }
-            }
-            if (next.empty()) break;
-            active.swap(next);
-            const int Bn2 = (int)active.size();
-            int B = 1; while (B < Bn2) B <<= 1;
+        std::vector<int> order;                         // job slot of each output token of this iteration
+        if (nd > 0) {
+            int B = nd;
+            if (segs.empty()) { B = 1; while (B < nd) B <<= 1; }      // the pure decode kernels come in power-of-two batch sizes
             for (int k = 0; k < B; ++k) {
-                const int kk = k < Bn2 ? k : 0;                         // padding slots replay slot 0 (same writes, ignored outputs)
-                Env& e = *es[active[kk]];
+                const int kk = k < nd ? k : 0;                          // padding slots replay slot 0 (same writes, ignored outputs)
+                Env& e = envs[jobs[dec[kk]].env];
                 REQUIRE(e.kv_len + 1 <= c.max_positions, "sequence exceeds max_positions during decode");
-                if (k < Bn2) ensure_pages(e, e.kv_len + 1);
+                if (k < nd) ensure_pages(e, e.kv_len + 1);
                 h_slots[k].page_table = e.d_pages; h_slots[k].pos = e.kv_len; h_slots[k].pad = 0;
-                h_tok_b[k] = next_tok[kk];
+                h_tok_b[k] = jobs[dec[kk]].last_tok;
             }
             HIP_CHECK(hipMemcpyAsync(d_slots, h_slots, B * sizeof(DecodeSlot), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(d_tok_b, h_tok_b, B * sizeof(int), hipMemcpyHostToDevice, st));
-            decode_ops_batched(B);
-            for (int k = 0; k < Bn2; ++k) {
-                Env& e = *es[active[k]];
-                e.kv_len += 1;
-                tap_copy(xn + (size_t)k * H, count[active[k]], active[k]);
+            if (segs.empty()) {
+                decode_ops_batched(B);                   // gather + 28 layers + head for B decode rows -> d_tok_b, xn = final-norm rows
+            } else {
+                launch_gather_rows<T>(st, d_tok_b, embed, feats, x, nd, H);
+            }
+            for (int k = 0; k < nd; ++k) order.push_back(dec[k]);
+        }
+        if (!segs.empty()) {
+            prefill_rows(segs, M, nd);
+            // last row of every job of this iteration -> one lm_head pass
+            const int nj = nd + (int)segs.size();
+            for (int k = 0; k < nd; ++k)
+                HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)k * H, x + (size_t)k * H, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+            for (size_t q = 0; q < segs.size(); ++q) {
+                const T* last = x + (size_t)(segs[q].off + segs[q].Tn - 1) * H;
+                HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)(nd + q) * H, last, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+                order.push_back(pre_now[q]);
+            }
+            int Bp = 1; while (Bp < nj) Bp <<= 1;
+            for (int k = nj; k < Bp; ++k)
+                HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)k * H, last_rows, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+            head_batched(last_rows, Bp);
+        }
+        const int nj = (int)order.size();
+        for (int q = 0; q < nj; ++q) tap_copy(xn + (size_t)q * H, jobs[order[q]].count, order[q]);
+        HIP_CHECK(hipEventRecord(ph_ev[3], st));
+        HIP_CHECK(hipMemcpyAsync(h_tok_b, d_tok_b, nj * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        LAUNCH_CHECK("batch_step");
+        {
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, ph_ev[2], ph_ev[3])); ph_ms[segs.empty() ? 2 : 1] += t;
+            if (vision_pending) { HIP_CHECK(hipEventElapsedTime(&t, ph_ev[0], ph_ev[1])); ph_ms[0] += t; vision_pending = false; }
+        }
+        for (int q = 0; q < nj; ++q) {
+            Job& j = jobs[order[q]];
+            Env& e = envs[j.env];
+            const int tok = h_tok_b[q];
+            REQUIRE(tok >= 0 && tok < V, "non-finite logits: the arg-max found no finite value (check the weights / fp8 scales)");
+            if (j.prefill) { e.kv_len = e.n_embeds; j.prefill = false; }      // this iteration prefilled the turn
+            else e.kv_len += 1;                                               // ... or fed the previous token
+            j.out.push_back(tok);
+            j.count += 1;
+            j.last_tok = tok;
+            bool stop = j.count >= j.max_new;
+            for (int64_t id : j.eos) stop |= id == tok;
+            if (stop) {
+                j.finished = true;
+                n_generated_b[order[q]] = j.count;
+                finished_slots[(*n_finished)++] = order[q];
             }
         }
-        HIP_CHECK(hipEventRecord(ph_ev[4], st));
-        HIP_CHECK(hipEventSynchronize(ph_ev[4]));
-        { float t = 0.f; HIP_CHECK(hipEventElapsedTime(&t, ph_ev[3], ph_ev[4])); ph_ms[2] += t; }
-        for (int s = 0; s < n_envs; ++s) { n_out[s] = count[s]; n_generated_b[s] = count[s]; }
+        int running = 0;
+        for (int k = 0; k < MAXB; ++k) running += jobs[k].used && !jobs[k].finished;
+        return running;
+    }
+    void batch_result(int slot, int32_t* env, int64_t* out, int cap, int32_t* n_out) override {
+        REQUIRE(slot >= 0 && slot < MAXB && jobs[slot].used && jobs[slot].finished, "no finished turn in this slot");
+        Job& j = jobs[slot];
+        const int n = (int)j.out.size();
+        for (int k = 0; k < n && k < cap; ++k) out[k] = j.out[k];
+        *n_out = n; *env = j.env;
+        j.used = false;
+    }
+    // svln_generate on each listed env, executed together: submit all, iterate until all are done (all envs prefill in the first
+    // iteration and decode in lockstep afterwards: the special case of the scheduler in which every turn falls due at once)
+    void generate_batch(const int32_t* env_ids, int n_envs, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap,
+                        int32_t* n_out) override {
+        REQUIRE(n_envs >= 1 && n_envs <= MAXB, "1..8 envs per batch");
+        REQUIRE(max_new >= 1 && cap >= 1, "max_new_tokens must be >= 1");
+        for (int k = 0; k < MAXB; ++k) REQUIRE(!jobs[k].used, "svln_generate_batch needs an idle scheduler (turns are in flight)");
+        for (int s = 0; s < n_envs; ++s)
+            for (int t = 0; t < s; ++t) REQUIRE(env_ids[t] != env_ids[s], "duplicate env in batch");
+        std::vector<int> slots(n_envs);
+        try {
+            for (int s = 0; s < n_envs; ++s) slots[s] = batch_submit(env_ids[s], max_new < cap ? max_new : cap, eos, n_eos);
+            int32_t fin[MAXB], nf = 0;
+            while (batch_step(fin, &nf) > 0) {}
+        } catch (...) {
+            for (int k = 0; k < MAXB; ++k) jobs[k].used = false;
+            throw;
+        }
+        for (int s = 0; s < n_envs; ++s) {
+            int32_t env = 0;
+            batch_result(slots[s], &env, out + (size_t)s * cap, cap, &n_out[s]);
+        }
     }
     void get_hidden_batch(int slot, float* out, int max_rows, int32_t* n_rows) override {
         REQUIRE(slot >= 0 && slot < MAXB, "slot");
@@ -1190,6 +1265,21 @@ public:
         }
         sync();
     }
+    void op_gemv_batched(GemvBatchArgs a, int32_t* host_tokens) override {
+        REQUIRE(a.B == 1 || a.B == 2 || a.B == 4 || a.B == 8, "B must be 1, 2, 4 or 8");
+        REQUIRE(a.K % Elt<T>::PER_CHUNK == 0 && a.N >= 1, "bad GEMV extents");
+        REQUIRE(a.epi != EPI_SWIGLU || a.N % 64 == 0, "SwiGLU needs N % 64 == 0 (32-row gate / up blocks)");
+        a.part_val = part_val_b; a.part_idx = part_idx_b;
+        launch_gemv_batched<T>(st, a);
+        if (a.epi == EPI_ARGMAX) {
+            launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(a.N, EPI_ARGMAX, a.B), a.B, d_tok_b);
+            HIP_CHECK(hipMemcpyAsync(h_tok_b, d_tok_b, a.B * sizeof(int), hipMemcpyDeviceToHost, st));
+            sync();
+            if (host_tokens) for (int b = 0; b < a.B; ++b) host_tokens[b] = h_tok_b[b];
+        }
+        sync();
+        LAUNCH_CHECK("op_gemv_batched");
+    }
     void op_quant_fp8(const void* w, int64_t rows, int cols, void* w8, float* scale) override {
         REQUIRE(sizeof(T) == 2, "fp8 quantisation reads bf16 weights");
         REQUIRE(cols % 16 == 0, "cols must be a multiple of 16");
@@ -1288,6 +1378,21 @@ int svln_generate_batch(svln_engine* h, const int32_t* envs, int n_envs, int max
                         int32_t* n_out) {
     API_BEGIN_H h->impl->generate_batch(envs, n_envs, max_new, eos, n_eos, out, cap, n_out); API_END
 }
+int svln_batch_submit(svln_engine* h, int env, int max_new_tokens, const int64_t* eos_ids, int n_eos, int32_t* slot) {
+    API_BEGIN_H
+    REQUIRE(slot, "null slot pointer");
+    *slot = h->impl->batch_submit(env, max_new_tokens, eos_ids, n_eos);
+    API_END
+}
+int svln_batch_step(svln_engine* h, int32_t* running, int32_t* finished_slots, int32_t* n_finished) {
+    API_BEGIN_H
+    REQUIRE(running && finished_slots && n_finished, "null output pointer");
+    *running = h->impl->batch_step(finished_slots, n_finished);
+    API_END
+}
+int svln_batch_result(svln_engine* h, int slot, int32_t* env, int64_t* out_ids, int out_cap, int32_t* n_out) {
+    API_BEGIN_H h->impl->batch_result(slot, env, out_ids, out_cap, n_out); API_END
+}
 int svln_get_hidden_batch(svln_engine* h, int slot, float* out, int max_rows, int32_t* n_rows) { API_BEGIN_H h->impl->get_hidden_batch(slot, out, max_rows, n_rows); API_END }
 int svln_generate(svln_engine* h, int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) {
     API_BEGIN_H h->impl->generate(env, max_new, eos, n_eos, out, cap, n_out, false); API_END
@@ -1336,6 +1441,14 @@ int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const vo
     GemvArgs a; a.W = W; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
     a.part_val = nullptr; a.part_idx = nullptr; a.w8 = nullptr; a.scale = nullptr; a.skip = nullptr;
     h->impl->op_gemv(a, host_token);
+    API_END
+}
+int svln_op_gemv_batched(svln_engine* h, const void* W, int ldw, const void* x, int ldx, const void* norm_w, float eps, const void* bias,
+                         const void* res, int ldr, void* y, int ldy, int N, int K, int epi, int B, int32_t* host_tokens) {
+    API_BEGIN_H
+    GemvBatchArgs a; a.W = W; a.ldw = ldw; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.ldr = ldr;
+    a.y = y; a.ldy = ldy; a.N = N; a.K = K; a.epi = epi; a.B = B; a.part_val = nullptr; a.part_idx = nullptr;
+    h->impl->op_gemv_batched(a, host_tokens);
     API_END
 }
 int svln_op_quant_fp8(svln_engine* h, const void* w_bf16, int64_t rows, int cols, void* w8, float* scale) {

@@ -432,6 +432,46 @@ class StreamVLNForCausalLM:
                                              out.ctypes.data_as(C.POINTER(C.c_int64)), cap, n_out.ctypes.data_as(C.POINTER(C.c_int32))))
         return [self._result(p[5], out[k, : n_out[k]], requests[k].get("inputs")) for k, p in enumerate(parsed)]
 
+    # ---- iteration-level scheduler: envs whose turns fall due at different times (streamvln_dagger.py:232-313) ----
+    @torch.no_grad()
+    def submit(self, inputs=None, images=None, **kwargs):
+        """Start one env's turn without waiting for it: same arguments as `generate`.  The turn joins the next `step_batch`
+        iteration, sharing its pass over the weights with whatever the other envs in flight are doing (prefill or decode).
+        Returns a ticket; the result arrives from `step_batch`."""
+        ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
+        on_dev = int(pix.is_cuda)
+        if on_dev:
+            torch.cuda.synchronize(pix.device)
+        _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+        self._begin_turn(env_id, past)
+        ids_np = np.ascontiguousarray(ids.numpy())
+        _check(self._lib.svln_append_turn(self._h, self._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
+        eos_np = np.asarray(eos, dtype=np.int64)
+        slot = C.c_int32()
+        _check(self._lib.svln_batch_submit(self._h, self._slot(env_id), min(max_new, self.cfg.max_positions),
+                                           eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size, C.byref(slot)))
+        if not hasattr(self, "_tickets"):
+            self._tickets = {}
+        self._tickets[slot.value] = (env_id, inputs)
+        return SimpleNamespace(env_id=env_id, slot=slot.value)
+
+    @torch.no_grad()
+    def step_batch(self):
+        """One scheduler iteration (one pass over the weights for every turn in flight).  Returns (finished, running): `finished` is
+        a list of (ticket, GenerateOutput) for the turns that ended in this iteration, `running` the number still in flight."""
+        running, nf = C.c_int32(), C.c_int32()
+        fin = (C.c_int32 * 8)()
+        _check(self._lib.svln_batch_step(self._h, C.byref(running), fin, C.byref(nf)))
+        done = []
+        cap = self.cfg.max_positions
+        for k in range(nf.value):
+            out = np.zeros(cap, dtype=np.int64)
+            n, env = C.c_int32(), C.c_int32()
+            _check(self._lib.svln_batch_result(self._h, fin[k], C.byref(env), out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n)))
+            env_id, inputs = self._tickets.pop(fin[k])
+            done.append((SimpleNamespace(env_id=env_id, slot=fin[k]), self._result(env_id, out[: n.value], inputs)))
+        return done, running.value
+
     def last_hidden_batch(self, slot: int) -> np.ndarray:
         buf = np.empty((8, self.cfg.hidden), dtype=np.float32)
         n = C.c_int32()

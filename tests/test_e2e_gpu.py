@@ -591,3 +591,112 @@ def test_batched_lockstep_envs_equal_solo_runs(dtype):
         req = agents[0]._build_request("")
         m.generate_batch([req, dict(req)])                      # duplicate env
     m.close()
+
+
+# ----------------------------------------------------------------------------------------------- multi-env turns vs the ORACLE
+def _oracle_env_logs(sc, n_envs, lengths, n_turns, env_steps=None):
+    """every env alone on the CPU oracle: same prompts (seed 7 + 31 e), same frames (env e's stream), same action-count rule"""
+    from oracle import streamvln_oracle as O
+    from streamvln_amd import weights as W
+    from streamvln_amd.agent import StreamingAgent
+    from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+    cfg = sc["cfg"]
+    sd = W.synth_state_dict(cfg, SEED)
+    logs = []
+    for e in range(n_envs):
+        orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"])
+        enc = SyntheticPromptEncoder(cfg, seed=7 + 31 * e, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
+        ag = StreamingAgent(orc, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"], num_history=sc["num_history"],
+                            max_new_tokens=sc["max_new"], eos_token_ids=eos_ids(sc), preprocess=lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb)))
+        ag.decode_actions = lambda ids, ag=ag, e=e: [1] * lengths(e, len(ag.turn_log) - 1)
+        while len(ag.turn_log) < n_turns[e]:
+            ag.act(synthetic_frame(e, ag.step_id))
+        logs.append(ag.turn_log)
+    return logs
+
+
+def test_ragged_multi_env_scheduler_vs_oracle():
+    """SURVEY 8f-1 / streamvln_dagger.py:232-313: 8 envs on one GPU whose model turns fall due at different times (staggered starts,
+    2 or 4 env steps per turn depending on env and turn), driven through submit / step_batch: envs prefill a new turn (incl. window
+    restarts with a <memory> block) in the same weight pass in which others decode.  Every env must reproduce what it produces ALONE
+    on the fp32 CPU oracle: ids identical, hidden <= 1e-3, cache lengths equal."""
+    from streamvln_amd.agent import AsyncBatchedAgents, StreamingAgent
+    from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+    sc = SCENARIOS["tiny_episode"]
+    cfg, N = sc["cfg"], 8
+    m = StreamVLNForCausalLM(cfg, dtype=torch.float32, max_envs=N, max_frames=3, max_positions=2048)
+    m.load_synthetic(SEED)
+    m.model.num_history = sc["num_history"]
+    proc = m.get_vision_tower().image_processor
+    lengths = lambda e, t: 2 if (e + t) % 2 == 0 else 4            # env steps until env e's next model turn: keeps 12 | turn steps
+    agents = []
+    for e in range(N):
+        enc = SyntheticPromptEncoder(cfg, seed=7 + 31 * e, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
+        ag = StreamingAgent(m, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"], num_history=sc["num_history"], env_id=e,
+                            device="cuda", max_new_tokens=sc["max_new"], eos_token_ids=eos_ids(sc), preprocess=proc.preprocess_array)
+        ag.decode_actions = lambda ids, ag=ag, e=e: [1] * lengths(e, len(ag.turn_log) - 1)
+        agents.append(ag)
+    hidden = [[] for _ in range(N)]
+
+    def on_result(i, ticket, out):
+        hidden[i].append(m.last_hidden_batch(ticket.slot))
+    group = AsyncBatchedAgents(agents, on_result=on_result)
+    for tick in range(90):
+        active = {i for i in range(N) if tick >= i}               # env i starts one tick after env i-1
+        group.tick([synthetic_frame(i, agents[i].step_id) for i in range(N)], active=active)
+    n_turns = [len(a.turn_log) for a in agents]
+    st = group.stats
+    assert min(n_turns) >= 4 and any(r["memory"] for a in agents for r in a.turn_log), n_turns      # window restarts happened
+    assert st["max_in_flight"] >= 4 and st["mixed_iterations"] >= 8, st              # prefilling and decoding envs shared weight passes
+    logs_o = _oracle_env_logs(sc, N, lengths, n_turns)
+    worst = 0.0
+    for e in range(N):
+        for t, (g, o) in enumerate(zip(agents[e].turn_log, logs_o[e])):
+            assert g["step_id"] == o["step_id"] and g["views"] == o["views"] and g["memory"] == o["memory"], (e, t)
+            assert g["out"].sequences[0].tolist() == o["out"].sequences[0].tolist(), (e, t)
+            assert g["out"].past_key_values.get_seq_length() == o["out"].cache_len, (e, t)
+            ho = o["out"].hidden.numpy()
+            hg = hidden[e][t]
+            k = min(len(hg), len(ho))
+            err = float(np.abs(hg[:k] - ho[:k]).max())
+            worst = max(worst, err)
+            assert err <= HIDDEN_TOL, (e, t, err)
+    print(f"ragged scheduler: {sum(n_turns)} turns of {N} envs vs the oracle, ids identical, worst hidden err {worst:.2e}, {st}")
+    m.close()
+
+
+def test_eight_env_lockstep_generate_batch_vs_oracle():
+    """BASELINE configs[4] shape: 8 envs stepped in lockstep through generate_batch (what bench.py's batched pass runs), fp32 TINY,
+    against 8 solo oracle envs: ids identical, hidden <= 1e-3 -- through two window restarts."""
+    from streamvln_amd.agent import BatchedAgents, StreamingAgent
+    from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
+    sc = SCENARIOS["tiny_episode"]
+    cfg, N = sc["cfg"], 8
+    m = StreamVLNForCausalLM(cfg, dtype=torch.float32, max_envs=N, max_frames=3 * N, max_positions=2048)
+    m.load_synthetic(SEED)
+    m.model.num_history = sc["num_history"]
+    proc = m.get_vision_tower().image_processor
+    agents = []
+    for e in range(N):
+        enc = SyntheticPromptEncoder(cfg, seed=7 + 31 * e, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
+        agents.append(StreamingAgent(m, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"], num_history=sc["num_history"], env_id=e,
+                                     device="cuda", max_new_tokens=sc["max_new"], eos_token_ids=eos_ids(sc), preprocess=proc.preprocess_array))
+    group = BatchedAgents(agents)
+    hidden = [[] for _ in range(N)]
+    for step in range(28):
+        n0 = len(agents[0].turn_log)
+        group.act([synthetic_frame(e, step) for e in range(N)])
+        if len(agents[0].turn_log) > n0:
+            for e in range(N):
+                hidden[e].append(m.last_hidden_batch(e))
+    n_turns = [len(a.turn_log) for a in agents]
+    assert n_turns == [7] * N
+    logs_o = _oracle_env_logs(sc, N, lambda e, t: 4, n_turns)
+    for e in range(N):
+        for t, (g, o) in enumerate(zip(agents[e].turn_log, logs_o[e])):
+            assert g["out"].sequences[0].tolist() == o["out"].sequences[0].tolist(), (e, t)
+            ho, hg = o["out"].hidden.numpy(), hidden[e][t]
+            k = min(len(hg), len(ho))
+            assert np.abs(hg[:k] - ho[:k]).max() <= HIDDEN_TOL, (e, t)
+            assert g["out"].past_key_values.get_seq_length() == o["out"].cache_len, (e, t)
+    m.close()

@@ -230,6 +230,51 @@ def test_gemv_swiglu_and_argmax(dtype):
     assert tok.value == 77, tok.value
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B", [1, 2, 4, 8])
+def test_gemv_batched_true_width(dtype, B):
+    """gemv_batched_kernel (decode step of <= 2 lockstep envs, lm_head arg-max at every batch size) at the true hidden width 3584:
+    plain + bias + residual, fused RMSNorm, SwiGLU over the [gate 32 | up 32] packing, per-env arg-max with ties -> lowest index.
+    The bf16 instantiation takes the packed dot2 path (v_dot2_f32_bf16), which has no fp32 twin."""
+    m = engine(TINY, dtype)
+    K, N = 3584, 4608
+    x = q(rnd((B, K), 130 + B), dtype)
+    g = q(1 + rnd((K,), 31, 0.1), dtype)
+    W = q(rnd((N, K), 32, 0.03), dtype)
+    bias, res = q(rnd((N,), 33, 0.1), dtype), q(rnd((B, N), 34), dtype)
+    dW, dx, dg, db, dr = (t.to(dtype).cuda() for t in (W, x, g, bias, res))
+    y = torch.zeros((B, N), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv_batched(m._h, ptr(dW), K, ptr(dx), K, None, 1e-6, ptr(db), ptr(dr), N, ptr(y), N, N, K, _lib.EPI_NONE, B, None))
+    assert_close(y, x @ W.t() + bias + res, dtype, f"gemv_batched B={B}")
+    y.zero_()
+    chk(m._lib.svln_op_gemv_batched(m._h, ptr(dW), K, ptr(dx), K, ptr(dg), 1e-6, None, None, 0, ptr(y), N, N, K, _lib.EPI_NONE, B, None))
+    xe = torch.stack([O.rms_norm(x[b], g, 1e-6) for b in range(B)])
+    assert_close(y, xe @ W.t(), dtype, f"gemv_batched norm B={B}")
+    # SwiGLU: N = 2 I packed rows -> I outputs
+    I = N // 2
+    idx = torch.arange(I)
+    gate, up = W[(idx // 32) * 64 + idx % 32], W[(idx // 32) * 64 + 32 + idx % 32]
+    ys = torch.zeros((B, I), dtype=dtype, device="cuda")
+    chk(m._lib.svln_op_gemv_batched(m._h, ptr(dW), K, ptr(dx), K, ptr(dg), 1e-6, None, None, 0, ptr(ys), I, N, K, _lib.EPI_SWIGLU, B, None))
+    assert_close(ys, O.silu(xe @ gate.t()) * (xe @ up.t()), dtype, f"gemv_batched swiglu B={B}")
+    # arg-max per env; env 0 has an exact tie between rows 77 and 4000 (lowest index wins), ragged N
+    V = 4607
+    Wv = W[:V].clone()
+    Wv[77] = q(x[0] * 0.02, dtype)
+    Wv[4000] = Wv[77]
+    logits = x @ Wv.t()
+    assert int(torch.argmax(logits[0])) == 77 and float(logits[0, 77]) == float(logits[0, 4000])
+    toks = (C.c_int32 * 8)()
+    dWv = Wv.to(dtype).cuda()
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemv_batched(m._h, ptr(dWv), K, ptr(dx), K, None, 1e-6, None, None, 0, None, 0, V, K, _lib.EPI_ARGMAX, B, toks))
+    margins = torch.topk(logits, 2, dim=1).values
+    for b in range(B):
+        if b == 0 or float(margins[b, 0] - margins[b, 1]) > (1e-3 if dtype == torch.float32 else 5e-2):
+            assert toks[b] == int(torch.argmax(logits[b])), (b, toks[b])
+
+
 def test_forced_split_is_bounded_by_the_workspace():
     """svln_op_gemm(force_split=S) must not write S fp32 slabs past the split-K workspace: rejected with an error"""
     m = engine(TINY, torch.bfloat16)
