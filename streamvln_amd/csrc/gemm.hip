@@ -50,6 +50,8 @@ using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
+using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: products with few 128-wide column
+                                                             // tiles and a short K (ViT out_proj, N = K = 1152) get >= 200 workgroups WITHOUT a K split (no fp32 slabs)
 using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockstep decode of several envs): 2 waves, 20 KB stages, glds kernel only
 using CfgBig4 = TileCfg<256, 256, 2, 2, 128, false, 2>;      // 4 waves, wave tile 128x128 (4x4 accumulators in AGPRs): half the LDS fragment reads per MFMA       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
 
@@ -362,6 +364,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         } else if constexpr (MI == 4) {
             if (more) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]) : "n"(RD));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fa[k][2]), "+v"(fa[k][3]), "+v"(fb[k][0]), "+v"(fb[k][1]));
+        } else if constexpr (MI == 1) {
+            if (more) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[k][0]), "+v"(fb[k][0]), "+v"(fb[k][1]) : "n"(RD));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fb[k][0]), "+v"(fb[k][1]));
         } else {
             if (more) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fb[k][0]), "+v"(fb[k][1]) : "n"(RD));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k][0]), "+v"(fa[k][1]), "+v"(fb[k][0]), "+v"(fb[k][1]));
@@ -677,9 +682,23 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         return false;
     }
 
+    const int fc = a.force_cfg & 0xFFF;
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    // several row tiles, few 128-wide column tiles and a short K (one-frame ViT out_proj: 729 x 1152 x 1152): 64x64 tiles fill the chip
+    // without a K split -- no fp32 slabs, no reduce pass; the caller runs the following norm itself (launch_gemm returns false).
+    // Measured: 12.7 us against 14.1 + 6.2 (split + reduce); at K = 4304 (fc2) the split path wins, 20 + 6 against 36.
+    // (Also measured and NOT kept: a 4-deep ring for one-round 128x128 launches, 19.9 vs 19.4 us on ViT qkv; issuing the LDS-DMA
+    //  pieces of the next stage one by one between the MFMAs instead of as a burst ahead of them: 5-25 % slower on every config.)
+    const int tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    const bool want64 = a.zeros && a.M > 256 && a.N <= 2048 && a.K <= 2048 && tiles128 < 96 && tiles64 <= 512;
+    if ((want64 && a.force_split == 0 && fc == 0) || (fc == 64 && a.zeros)) {
+        a.nsplit = 1;
+        a.launch_tiles = tiles64;
+        launch_cfg<T, EPI, Cfg64, false>(s, a, 1);
+        return false;
+    }
     const bool want128 = a.M > 256 && tiles128 >= 96;
-    if ((want128 && a.force_split == 0) || (a.force_cfg & 0xFFF) == 128) {
+    if ((want128 && a.force_split == 0) || fc == 128) {
         a.nsplit = 1;
         a.launch_tiles = tiles128;
         if (tiles128 > 256 && a.zeros && !(a.force_cfg & 0x2000)) launch_cfg<T, EPI, Cfg128L, false>(s, a, 1);
@@ -746,6 +765,7 @@ template <typename T, int EPI> static void gemm_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg64::NBUF * Cfg64::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128L::NBUF * Cfg128L::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::NBUF * CfgBig::STAGE_BYTES);
 }

@@ -31,7 +31,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (32, 0), (32, 4)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles; 32 = 32x128 tiles (M <= 32 only)
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (32, 0), (32, 4), (64, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -39,6 +39,7 @@ def chk(rc):
     (130, 1152, 4304, _lib.EPI_NONE, True, True),        # ViT fc2: K not a multiple of the stage
     (64, 256, 592, _lib.EPI_GELU_ERF, True, False),      # patch-embed K
     (1, 128, 64, _lib.EPI_NONE, False, False),           # degenerate
+    (729, 1152, 1152, _lib.EPI_NONE, True, True),        # ViT out_proj at one frame: the heuristic takes 64x64 tiles, no K split
 ])
 def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     if cfgsplit[0] == 32 and M > 32:
@@ -72,8 +73,9 @@ def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     (212, 3584, 18944 // 8, 3, "rms", True),    # down_proj-like
     (1, 512, 512, 2, "rms", True),
     (700, 2048, 1024, 0, "rms", False),     # many 128x128 tiles -> unsplit: the caller must run the norm itself
-    (729, 1152, 1152, 0, "ln", True),       # SigLIP out_proj -> layer_norm2, one frame
-    (729, 1152, 4304, 0, "ln", True),       # SigLIP fc2 -> next layer_norm1
+    (729, 1152, 1152, 0, "ln", False),      # SigLIP out_proj, one frame: 64x64 tiles without a K split -> the caller runs layer_norm2
+    (729, 1152, 1152, 9, "ln", True),       # ... and with a forced K split the reduce emits it
+    (729, 1152, 4304, 8, "ln", True),       # SigLIP fc2 -> next layer_norm1
     (50, 144, 288, 2, "ln", True),
 ])
 def test_gemm_fused_norm(dtype, M, N, K, split, kind, expect_fused):
