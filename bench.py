@@ -314,13 +314,22 @@ def main():
         cached.update(hits=hits, misses=misses,
                       note="opt-in: pooled features of frames already encoded in the episode are reused (content hash) instead of "
                            "re-running the ViT on the 8 <memory> frames; not the headline value")
-    # opt-in fp8 (e4m3) decode weights (no reference counterpart).  Reduced precision -> never the headline value.
+    # opt-in fp8 (e4m3) LLM weights (no reference counterpart): decode GEMVs + lm_head stream the e4m3 copies, the prefill
+    # products run as e4m3 x e4m3 MFMA GEMMs with per-row activation scales.  Reduced precision -> never the headline value.
     fp8 = None
     if not a.no_fp8_pass and a.dtype == "bf16":
-        fp8 = extra_pass(lambda: model.set_fp8_decode(True), lambda: model.set_fp8_decode(False))
-        fp8.update(dtype="bf16 activations, e4m3 decode weights",
+        def fp8_on():
+            model.set_fp8_decode(True)
+            model.set_fp8_gemm(True)
+
+        def fp8_off():
+            model.set_fp8_decode(False)
+            model.set_fp8_gemm(False)
+        fp8 = extra_pass(fp8_on, fp8_off)
+        fp8.update(dtype="bf16 activations / e4m3 LLM weights (per-row scales); prefill GEMMs e4m3 x e4m3 MFMA with fp32 accumulate",
                    note="opt-in: decode-step GEMVs and lm_head stream per-row-scaled e4m3 copies of the LLM weights (half the HBM bytes per "
-                        "token); prefill and vision stay bf16; reduced precision, not the headline value")
+                        "token), prefill QKV / o / gate-up / down run as fp8 MFMA products; vision, attention and norms stay bf16; "
+                        "reduced precision, not the headline value")
     # opt-in slow-memory pruning (BASELINE configs[3] "32 pruned slow-memory tokens"; no reference counterpart, SURVEY a-13).
     pruned = None
     if not a.no_prune_pass:
@@ -355,8 +364,22 @@ def main():
         dtb = timed_pass(model, lockstep_turn, a.steps, a.warmup, world)
         batched = {"envs_per_gpu": n_benv, "value": round(NUM_FUTURE * n_benv * a.steps * world / dtb, 2), "unit": "action-steps/s",
                    "per_gpu": round(NUM_FUTURE * n_benv * a.steps / dtb, 2), "ms_per_lockstep_turn": round(dtb / a.steps * 1e3, 3),
+                   "dtype": "bf16",
                    "note": "BASELINE configs[4]-style: envs_per_gpu concurrent envs stepped in lockstep (batched prefill rows + batched "
                            "decode steps, bf16); not the headline value"}
+        if a.dtype == "bf16" and not a.no_fp8_pass:
+            # configs[4] as BASELINE.json words it: batch of concurrent envs + fp8 MFMA on the QKV / MLP GEMMs (prefill rows and the
+            # 32-row decode-step products of the batch); opt-in, reduced precision
+            model.set_fp8_gemm(True)
+            while bstep[0] != EP_STEPS:
+                lockstep_turn()
+            dt8 = timed_pass(model, lockstep_turn, a.steps, a.warmup, world)
+            model.set_fp8_gemm(False)
+            batched["fp8_mfma"] = {"value": round(NUM_FUTURE * n_benv * a.steps * world / dt8, 2), "unit": "action-steps/s",
+                                   "ms_per_lockstep_turn": round(dt8 / a.steps * 1e3, 3),
+                                   "dtype": "bf16 activations / e4m3 x e4m3 MFMA for the LLM's QKV, o, gate-up and down products (per-row "
+                                            "weight and activation scales, fp32 accumulate, bf16 out); lm_head, attention, vision bf16",
+                                   "note": "opt-in extension, no reference counterpart; reduced precision, never the headline"}
     # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
     summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
     turns_total = a.steps * world

@@ -111,6 +111,11 @@ int svln_set_decode_graph(svln_engine* h, int enable);     /* replay the per-tok
  * weights (one fp32 scale per output row, quantised on the device from the loaded tensors at the first enable) instead of the bf16
  * ones -- half the HBM bytes per generated token.  bf16 engines only; prefill, vision and svln_generate_batch keep bf16 weights. */
 int svln_set_fp8_decode(svln_engine* h, int enable);
+/* Opt-in, no reference counterpart (BASELINE configs[4] "fp8 MFMA on QKV/MLP GEMMs"): the LLM's dense products with more
+ * than one row -- prefill, and the decode steps of >= 4 envs batched by svln_generate_batch / svln_batch_step -- run as e4m3 x e4m3 MFMA
+ * products (fp32 accumulate, bf16 out) on the e4m3 weight copies above with per-row activation scales computed on the fly.  bf16 engines
+ * only; vision, attention, norms, lm_head and the batch-1 decode GEMVs are unaffected (the latter have svln_set_fp8_decode). */
+int svln_set_fp8_gemm(svln_engine* h, int enable);
 /* Opt-in slow-memory pruning (BASELINE configs[3]; the reference has NO counterpart -- its memory is all num_history x 196 pooled
  * tokens, streamvln_eval.py:313-321 -- so this is pinned only by the project's own CPU restatement, oracle: prune_memory_tokens):
  * with keep_tokens > 0 a `<memory>` sentinel expands to the keep_tokens memory tokens least similar (cosine) to the mean memory
@@ -140,6 +145,10 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
+/* the product behind svln_set_fp8_gemm: C [M][N] (bf16) = epi(a_scale[m] * w_scale[n] * (A8 [M][K] . W8 [N][K]^T) + bias) + res, e4m3 operands
+ * (svln_op_quant_fp8 makes them), epi = EPI_NONE or EPI_SWIGLU, K % 16 == 0 */
+int svln_op_gemm_fp8(svln_engine* h, const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
+                     const void* bias, const void* res, int ldr, int M, int N, int K, int epi, int force_cfg, int force_split);
 /* B (1, 2, 4 or 8) activation vectors x [B][ldx] against one weight stream (the decode step of svln_generate_batch / svln_batch_step at
  * B <= 2, and its lm_head at every B): y [B][ldy], res [B][ldr]; EPI_ARGMAX writes one token per vector to host_tokens[B] */
 int svln_op_gemv_batched(svln_engine* h, const void* W, int ldw, const void* x, int ldx, const void* norm_w, float eps, const void* bias,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "svln_get_top2": (_I, [_P, _PF]),
     "svln_set_decode_graph": (_I, [_P, _I]),
     "svln_set_fp8_decode": (_I, [_P, _I]),
+    "svln_set_fp8_gemm": (_I, [_P, _I]),
     "svln_set_memory_prune": (_I, [_P, _I]),
     "svln_op_memory_prune": (_I, [_P, _P, _I, _I, _PI32, _PF]),
     "svln_probe_reset": (_I, [_P]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemm_norm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _PI32]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
+    "svln_op_gemm_fp8": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemv_batched": (_I, [_P, _P, _I, _P, _I, _P, _F, _P, _P, _I, _P, _I, _I, _I, _I, _I, _PI32]),
     "svln_op_quant_fp8": (_I, [_P, _P, _I64, _I, _P, _P]),
     "svln_op_gemv_fp8": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),

@@ -20,7 +20,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define SVLN_DEV __device__ __forceinline__
 
+struct fp8_t { uint8_t v; };        // OCP e4m3 storage (operands of the opt-in fp8 MFMA products; never an output type)
 template <typename T> struct Elt;
+template <> struct Elt<fp8_t> { static constexpr int PER_CHUNK = 16; static constexpr int BYTES = 1; };
 template <> struct Elt<bf16> { static constexpr int PER_CHUNK = 8; static constexpr int BYTES = 2; };
 template <> struct Elt<float> { static constexpr int PER_CHUNK = 4; static constexpr int BYTES = 4; };
 
@@ -80,6 +82,16 @@ template <> SVLN_DEV void mma_chunk<float>(const uint4& a, const uint4& b, f32x1
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// e4m3 operands: a 16-byte chunk holds 16 k values = two v_mfma_f32_32x32x16_fp8_fp8 (8 bytes per lane each); both operands use the
+// same byte -> k assignment, so the products pair up correctly whatever the order inside the chunk.  Same rate as the bf16 MFMA,
+// half the operand bytes per k.
+template <> SVLN_DEV void mma_chunk<fp8_t>(const uint4& a, const uint4& b, f32x16& acc) {
+    const long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
+    const long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc, 0, 0, 0);
 }
 
 SVLN_DEV int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }

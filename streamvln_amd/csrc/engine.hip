@@ -88,6 +88,8 @@ struct EngineBase {
     virtual void sync() = 0;
     virtual void set_graph(int enable) = 0;
     virtual void set_fp8_decode(int enable) = 0;
+    virtual void set_fp8_gemm(int enable) = 0;
+    virtual bool op_gemm_fp8(const GemmArgs& a) = 0;
     virtual void set_memory_prune(int keep) = 0;
     virtual void op_memory_prune(const void* m, int n_rows, int keep, int32_t* out_idx, float* out_score) = 0;
     virtual void probe_reset() = 0;
@@ -125,6 +127,7 @@ public:
     struct Q8 { uint8_t* q = nullptr; float* s = nullptr; };      // fp8 (e4m3) copy of a weight matrix + per-row scales (opt-in decode mode)
     struct LLayer { T *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gu_w, *down_w, *kpool, *vpool; Q8 qkv8, o8, gu8, down8; };
     Q8 lm_head8; bool fp8_on = false, fp8_built = false;
+    bool fp8_gemm_on = false; uint8_t* act8 = nullptr; float* act8_scale = nullptr;      // opt-in fp8 MFMA products: quantised activation rows
     T *patch_w, *patch_b, *pos_emb, *proj0_w, *proj0_b, *proj2_w, *proj2_b, *embed, *final_norm, *lm_head;
     std::vector<VLayer> vl;
     std::vector<LLayer> ll;
@@ -436,7 +439,8 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr; return a;
+        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
+        a.a_scale = nullptr; a.w_scale = nullptr; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -717,7 +721,7 @@ public:
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
-            launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE));
+            llm_gemm(gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE), L.qkv8);
             if (n_dec > 0) {
                 AttnArgs a = batched_decode_attn_args(L, n_dec);
                 launch_attention<T>(st, a, 128, 1);
@@ -735,11 +739,11 @@ public:
             // the split-K reduce of o_proj / down_proj also emits the following RMSNorm when it can (T <= 256 rows)
             GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE);
             ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
-            if (!launch_gemm<T>(st, ao)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
-            launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU));
+            if (!llm_gemm(ao, L.o8)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
+            llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU), L.gu8);
             GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE);
             if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
-            xn_ready = launch_gemm<T>(st, ad);
+            xn_ready = llm_gemm(ad, L.down8);
         }
     }
     AttnArgs batched_decode_attn_args(const LLayer& L, int B) {
@@ -873,7 +877,7 @@ public:
             const LLayer& L = ll[i];
             // RMSNorm as its own tiny launch in the batched step (amortised over B envs)
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, B, H, c.rms_eps);
-            if (mfma) launch_gemm<T>(st, gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE));
+            if (mfma) llm_gemm(gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE), L.qkv8);
             else launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
             AttnArgs a = batched_decode_attn_args(L, B);
             launch_attention<T>(st, a, 128, 1);
@@ -881,11 +885,11 @@ public:
             if (mfma) {
                 GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, B, H, qd, EPI_NONE);
                 ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
-                if (!launch_gemm<T>(st, ao)) launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
-                launch_gemm<T>(st, gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, B, 2 * I, H, EPI_SWIGLU));
+                if (!llm_gemm(ao, L.o8)) launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
+                llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, B, 2 * I, H, EPI_SWIGLU), L.gu8);
                 GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, B, H, I, EPI_NONE);
                 if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
-                xn_ready = launch_gemm<T>(st, ad);
+                xn_ready = llm_gemm(ad, L.down8);
             } else {
                 launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));
                 launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
@@ -1199,29 +1203,69 @@ public:
     // Opt-in (no reference counterpart): the single-env decode step and the lm_head read e4m3 copies of the LLM
     // weights (per-row scale) instead of the bf16 ones; prefill, vision and the lockstep multi-env path keep bf16.  Both copies stay
     // resident (15.2 + 7.6 GB of 288).  Quantised from the tensors loaded at the time of the first enable.
+    void build_fp8_weights() {
+        REQUIRE(sizeof(T) == 2, "fp8 weights need the bf16 engine");
+        REQUIRE(weights_missing() == 0, g_err);
+        REQUIRE(H % 16 == 0 && I % 16 == 0, "fp8 weights need hidden and intermediate sizes that are multiples of 16");
+        if (fp8_built) return;
+        auto build = [&](Q8& q, const T* w, int64_t rows, int cols) {
+            q.q = dalloc<uint8_t>((size_t)rows * cols);
+            q.s = dalloc<float>((size_t)rows);
+            launch_quant_fp8_rows(st, w, cols, q.q, q.s, rows, cols);
+        };
+        for (auto& L : ll) {
+            build(L.qkv8, L.qkv_w, qkv_dim, H);
+            build(L.o8, L.o_w, H, nq * 128);
+            build(L.gu8, L.gu_w, 2 * I, H);
+            build(L.down8, L.down_w, H, I);
+        }
+        build(lm_head8, lm_head, V, H);
+        HIP_CHECK(hipStreamSynchronize(st));
+        fp8_built = true;
+    }
     void set_fp8_decode(int enable) override {
         if (!enable) { if (fp8_on) drop_graphs(); fp8_on = false; return; }
-        REQUIRE(sizeof(T) == 2, "fp8 decode weights need the bf16 engine");
-        REQUIRE(weights_missing() == 0, g_err);
-        REQUIRE(H % 16 == 0 && I % 16 == 0, "fp8 decode weights need hidden and intermediate sizes that are multiples of 16");
-        if (!fp8_built) {
-            auto build = [&](Q8& q, const T* w, int64_t rows, int cols) {
-                q.q = dalloc<uint8_t>((size_t)rows * cols);
-                q.s = dalloc<float>((size_t)rows);
-                launch_quant_fp8_rows(st, w, cols, q.q, q.s, rows, cols);
-            };
-            for (auto& L : ll) {
-                build(L.qkv8, L.qkv_w, qkv_dim, H);
-                build(L.o8, L.o_w, H, nq * 128);
-                build(L.gu8, L.gu_w, 2 * I, H);
-                build(L.down8, L.down_w, H, I);
-            }
-            build(lm_head8, lm_head, V, H);
-            HIP_CHECK(hipStreamSynchronize(st));
-            fp8_built = true;
-        }
+        build_fp8_weights();
         if (!fp8_on) drop_graphs();
         fp8_on = true;
+    }
+    // Opt-in (no reference counterpart): the LLM's dense products with more than one row -- prefill (svln_generate,
+    // the scheduler) and the decode steps of >= 4 lockstep envs -- run as e4m3 x e4m3 MFMA products (v_mfma_f32_32x32x16_fp8_fp8, fp32
+    // accumulate, bf16 out): per-row weight scales (the copies of svln_set_fp8_decode), per-row activation scales computed on the fly.
+    // Half the operand bytes per k through HBM / L2 / LDS.  Vision, attention, norms and the lm_head stay bf16.
+    void set_fp8_gemm(int enable) override {
+        if (!enable) { fp8_gemm_on = false; return; }
+        build_fp8_weights();
+        if (!act8) {
+            const size_t widest = (size_t)(I > nq * 128 ? I : nq * 128);
+            act8 = dalloc<uint8_t>((size_t)c.max_positions * (widest > (size_t)H ? widest : (size_t)H));
+            act8_scale = dalloc<float>((size_t)c.max_positions);
+        }
+        fp8_gemm_on = true;
+    }
+    // C = A . W^T (+ epilogue) for an LLM linear: bf16 operands, or -- with svln_set_fp8_gemm -- the rows of A quantised on the fly
+    // against the e4m3 copy of W
+    bool llm_gemm(GemmArgs a, const Q8& q) {
+        if (fp8_gemm_on && q.q) {
+            launch_quant_fp8_rows(st, a.A, a.lda, act8, act8_scale, a.M, a.K);
+            a.A = act8; a.lda = a.K; a.W = q.q; a.ldw = a.K; a.a_scale = act8_scale; a.w_scale = q.s;
+        }
+        return launch_gemm<T>(st, a);
+    }
+    bool op_gemm_fp8(const GemmArgs& a0) override {
+        REQUIRE(sizeof(T) == 2, "fp8 products need the bf16 engine");
+        GemmArgs a = a0; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.zeros = zero_line;
+        REQUIRE(a.a_scale && a.w_scale, "missing scales");
+        REQUIRE(a.K % 16 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0, "K and the row strides must be multiples of 16");
+        REQUIRE(a.epi == EPI_NONE || a.epi == EPI_SWIGLU, "fp8 products: plain or SwiGLU epilogue");
+        if (a.force_split > 1) {
+            REQUIRE((size_t)a.force_split * a.M * a.N <= gemm_ws_elems, "force_split: S * M * N exceeds the split-K workspace");
+            REQUIRE(a.N % 4 == 0 && !(a.epi == EPI_SWIGLU && a.N % 64 != 0), "force_split: N must be a multiple of 4 (64 with SwiGLU)");
+        }
+        const bool fused = launch_gemm<T>(st, a);
+        sync();
+        LAUNCH_CHECK("op_gemm_fp8");
+        return fused;
     }
     void probe_reset() override {
         if (probe_ev.empty()) { probe_ev.resize(4096); for (auto& ev : probe_ev) HIP_CHECK(hipEventCreate(&ev)); }
@@ -1406,6 +1450,7 @@ int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEG
 int svln_get_top2(svln_engine* h, float* out) { API_BEGIN_H h->impl->get_top2(out); API_END }
 int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_graph(enable); API_END }
 int svln_set_fp8_decode(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_fp8_decode(enable); API_END }
+int svln_set_fp8_gemm(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_fp8_gemm(enable); API_END }
 int svln_set_memory_prune(svln_engine* h, int keep_tokens) { API_BEGIN_H h->impl->set_memory_prune(keep_tokens); API_END }
 int svln_op_memory_prune(svln_engine* h, const void* mem, int n_rows, int keep, int32_t* out_idx, float* out_score) {
     API_BEGIN_H h->impl->op_memory_prune(mem, n_rows, keep, out_idx, out_score); API_END
@@ -1441,6 +1486,15 @@ int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const vo
     GemvArgs a; a.W = W; a.ldw = ldw; a.x = x; a.norm_w = norm_w; a.eps = eps; a.bias = bias; a.res = res; a.y = y; a.N = N; a.K = K; a.epi = epi;
     a.part_val = nullptr; a.part_idx = nullptr; a.w8 = nullptr; a.scale = nullptr; a.skip = nullptr;
     h->impl->op_gemv(a, host_token);
+    API_END
+}
+int svln_op_gemm_fp8(svln_engine* h, const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
+                     const void* bias, const void* res, int ldr, int M, int N, int K, int epi, int force_cfg, int force_split) {
+    API_BEGIN_H
+    GemmArgs a; std::memset(&a, 0, sizeof(a));
+    a.A = A8; a.lda = lda; a.W = W8; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.a_scale = a_scale; a.w_scale = w_scale;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.nsplit = 1; a.force_cfg = force_cfg; a.force_split = force_split;
+    h->impl->op_gemm_fp8(a);
     API_END
 }
 int svln_op_gemv_batched(svln_engine* h, const void* W, int ldw, const void* x, int ldx, const void* norm_w, float eps, const void* bias,

@@ -261,10 +261,11 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // Ring of NBUF stage buffers, NBUF-1 stages in flight behind a counted s_waitcnt vmcnt + one raw s_barrier per stage:
 //   wait(stage i landed) ; barrier ; issue stage i+NBUF-1 into the buffer read in iteration i-1 ; MFMAs on stage i.
 // Rows beyond M / N are clamped to the last valid row (their outputs are never stored); K-tail chunks read a zero line.
-template <typename T, int EPI, typename C, bool SPLITK>
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T>
 __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int EPC = Elt<T>::PER_CHUNK;
+    constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
+    constexpr bool FP8 = sizeof(TA) == 1;
     static_assert(C::ROWB == 128 && C::CH == 8, "glds path: 128-byte tile rows (4 macro steps per stage)");
     constexpr int WAVES = C::THREADS / 64;
     constexpr int BLK_A = C::BM * C::ROWB / 1024, BLK_W = C::BN * C::ROWB / 1024;
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
         cj[j] = c;
         loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
-        if (isA) src[j] = (const char*)((const T*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
-        else src[j] = (const char*)((const T*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
+        if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
+        else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
     }
     auto issue = [&](int st, int buf) {
         char* base = smem + buf * C::STAGE_BYTES;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const u32x4 a4 = fa[s & 1][i], b4 = fb[s & 1][j];
-                        mma_chunk<T>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
+                        mma_chunk<TA>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
                         if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo);
                         ++q;
                         __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const u32x4 a4 = fa[s & 1][i], b4 = fb[s & 1][j];
-                    mma_chunk<T>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
+                    mma_chunk<TA>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
                 }
             __builtin_amdgcn_sched_barrier(0);      // keep step s's MFMAs ahead of step s+1's wait
         }
@@ -431,6 +432,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
     }
 
+    if (FP8) {           // dequantise (linear, so split-K partials are scaled too): per-row activation scale x per-row weight scale
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float sw = p.w_scale[min(col0 + wc * WCOLS + j * 32 + r32, p.N - 1)];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= sw * p.a_scale[min(row0 + wr * WROWS + i * 32 + acc_row(r, lane), p.M - 1)];
+        }
+    }
     if (SPLITK) {
         float* slab = p.ws + (size_t)ks * p.M * p.N;
 #pragma unroll
@@ -616,8 +627,14 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
     if constexpr (C::MI == 2 && C::NJ == 2) {
-        if (!a.zeros || (a.force_cfg & 0x2000)) {          // register-staged kernel (64x64 wave tiles only)
+        if ((!a.zeros || (a.force_cfg & 0x2000)) && !a.a_scale) {          // register-staged kernel (64x64 wave tiles only; bf16 / fp32 operands)
             hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
+            return;
+        }
+    }
+    if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
+        if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
             return;
         }
     }
@@ -643,7 +660,7 @@ template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_
 
 template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return false;
-    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const int EPC = a.a_scale ? 16 : Elt<T>::PER_CHUNK;      // 16-byte chunks of K: e4m3 operands hold 16 values per chunk
     a.tile_base = 0;
     if (a.force_split > 1) {      // a forced split obeys the same workspace / shape limits as the heuristic ones
         const bool ok = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
@@ -678,7 +695,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if ((tilesbig >= 256 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
         a.nsplit = 1;
         a.launch_tiles = tilesbig;
-        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CfgBig, false>), dim3(tilesbig), dim3(CfgBig::THREADS), CfgBig::NBUF * CfgBig::STAGE_BYTES, s, a);
+        launch_cfg<T, EPI, CfgBig, false>(s, a, 1);
         return false;
     }
 
@@ -768,6 +785,16 @@ template <typename T, int EPI> static void gemm_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg64::NBUF * Cfg64::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128L::NBUF * Cfg128L::STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::NBUF * CfgBig::STAGE_BYTES);
+    if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128::NBUF * Cfg128::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg64, false, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg64::NBUF * Cfg64::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg128L::NBUF * Cfg128L::STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, CfgBig, false, fp8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::NBUF * CfgBig::STAGE_BYTES);
+    }
 }
 void gemm_init_attrs() {
     gemm_attr<bf16, EPI_NONE>(); gemm_attr<bf16, EPI_GELU_TANH>(); gemm_attr<bf16, EPI_GELU_ERF>(); gemm_attr<bf16, EPI_SWIGLU>();

@@ -30,6 +30,9 @@ struct GemmArgs {
     // launch_gemm returns true; otherwise norm_out is untouched (false) and the caller runs launch_rmsnorm itself
     const void* norm_w; void* norm_out; float norm_eps;
     const void* norm_b;           // non-null: LayerNorm (mean/variance, weight norm_w, bias norm_b) instead of RMSNorm -- the ViT's ln1 / ln2
+    // opt-in fp8 (OCP e4m3) operands (bf16 engine): when a_scale is set, A [M][K] and W [N][K] are e4m3 bytes (lda / ldw in
+    // elements), C = a_scale[m] * w_scale[n] * (A . W^T) then the usual epilogue in bf16; K % 16 == 0
+    const float* a_scale; const float* w_scale;
     int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced

@@ -523,6 +523,11 @@ class StreamVLNForCausalLM:
         weights (per-row scale).  Prefill, vision and generate_batch keep bf16.  bf16 engines only."""
         _check(self._lib.svln_set_fp8_decode(self._h, int(enable)))
 
+    def set_fp8_gemm(self, enable: bool):
+        """Opt-in extension (SURVEY.md 8f-2 / BASELINE configs[4]): the LLM's multi-row products (prefill; decode steps of >= 4 batched
+        envs) run as e4m3 MFMA products with per-row weight and activation scales.  bf16 engines only; reduced precision."""
+        _check(self._lib.svln_set_fp8_gemm(self._h, int(enable)))
+
     def sync(self):
         _check(self._lib.svln_sync(self._h))
 

@@ -226,6 +226,62 @@ def test_reference_harness_env_ids_map_onto_engine_slots():
     m.close()
 
 
+def test_fp8_mfma_gemms_opt_in():
+    """SURVEY 8f-2 / BASELINE configs[4] (no reference oracle: the reference is bf16 only): with svln_set_fp8_gemm the LLM's prefill
+    products -- and, in generate_batch with >= 4 envs, the decode-step products -- are e4m3 MFMA products.  Reported: id agreement
+    with the bf16 run before the first divergence and the relative error of the hidden states; switching it off restores bf16 exactly."""
+    from streamvln_amd.synthetic import synthetic_frame
+    sc = dict(SCENARIOS["tiny_episode"], eos_mod=0)
+    m = _model(sc, torch.bfloat16)
+    log0, taps0 = _run(m, sc)
+    m.set_fp8_gemm(True)
+    m.reset(1)
+    log8, taps8 = _run(m, sc)
+    assert [tp["cache_len"] for tp in taps8] == [tp["cache_len"] for tp in taps0]
+    agree = total = 0
+    worst = 0.0
+    for t, (r0, r8) in enumerate(zip(log0, log8)):
+        ids0, ids8 = r0["out"].sequences[0].tolist(), r8["out"].sequences[0].tolist()
+        n = 0
+        while n < len(ids0) and ids0[n] == ids8[n]:
+            n += 1
+        agree += n; total += len(ids0)
+        k = min(n + 1, len(ids0))
+        ref = taps0[t]["hidden"][:k].astype(np.float64)
+        worst = max(worst, float(np.linalg.norm(taps8[t]["hidden"][:k] - ref) / np.linalg.norm(ref)))
+        if n < len(ids0):
+            break
+    assert worst < 0.10 and agree >= 1, (worst, agree, total)
+    print(f"fp8 MFMA GEMMs: {agree}/{total} token ids agree with bf16 before the first divergence, hidden rel err {worst:.4f}")
+    # 4 envs through generate_batch: the batched decode steps take the 32-row fp8 MFMA path; per-env results = the solo fp8 runs' first turn
+    m.close()
+    m = StreamVLNForCausalLM(sc["cfg"], dtype=torch.bfloat16, max_envs=4, max_frames=4, max_positions=1024)
+    m.load_synthetic(SEED)
+    m.model.num_history = 2
+    m.set_fp8_gemm(True)
+    reqs = []
+    for e in range(4):
+        ids, img = _first_turn_inputs(m, sc, step=e, seed=20 + e)
+        reqs.append(dict(inputs=ids, images=img, env_id=e, time_ids=[[0]]))
+    outs = m.generate_batch(reqs, max_new_tokens=4, eos_token_ids=[])
+    hb = [m.last_hidden_batch(e) for e in range(4)]
+    m.set_fp8_gemm(False)
+    m.reset(4)
+    outs16 = m.generate_batch(reqs, max_new_tokens=4, eos_token_ids=[])
+    for e in range(4):
+        h16 = m.last_hidden_batch(e)
+        assert outs[e].sequences.shape == (1, 4)
+        rel = float(np.linalg.norm(hb[e][0] - h16[0]) / np.linalg.norm(h16[0]))      # first token: prefill only
+        assert rel < 0.10, (e, rel)
+    m.reset(1)
+    logb, tapsb = [], []
+    m.close()
+    m32 = _model(SCENARIOS["tiny_episode"], torch.float32)
+    with pytest.raises(Exception, match="bf16"):
+        m32.set_fp8_gemm(True)
+    m32.close()
+
+
 def test_operator_surface_errors():
     sc = SCENARIOS["tiny_episode"]
     m = _model(sc, torch.bfloat16)

@@ -373,6 +373,52 @@ def test_gemv_fp8_weights(N, K, norm, bias, res):
     assert rel < 0.05, rel
 
 
+@pytest.mark.parametrize("M,N,K,epi,bias,res,cfgsplit", [
+    (212, 512, 3584, _lib.EPI_NONE, True, True, (0, 0)),        # steady prefill rows: 256x128 tiles, heuristic K split
+    (212, 1024, 3584, _lib.EPI_SWIGLU, False, False, (0, 0)),   # gate/up with the SwiGLU epilogue
+    (212, 3584, 18944 // 4, _lib.EPI_NONE, False, True, (0, 3)),  # down_proj-like, forced 3-way split
+    (8, 4608, 3584, _lib.EPI_NONE, True, False, (0, 0)),        # 8 lockstep envs: 32x128 tiles
+    (5, 2048, 1024, _lib.EPI_SWIGLU, False, False, (32, 2)),
+    (600, 2048, 1024, _lib.EPI_NONE, True, False, (0, 0)),      # 128x128 tiles
+    (700, 1024, 512, _lib.EPI_NONE, False, False, (256, 0)),    # 256x256 tiles
+    (300, 384, 1152, _lib.EPI_NONE, True, True, (64, 0)),       # 64x64 tiles
+])
+def test_gemm_fp8_mfma(M, N, K, epi, bias, res, cfgsplit):
+    """e4m3 x e4m3 MFMA product with per-row scales on both operands (svln_set_fp8_gemm) against the fp32 product of the
+    DEQUANTISED operands (quantisation error is the model's business, not the kernel's)."""
+    dtype = torch.bfloat16
+    m = engine(TINY, dtype)
+    A = q(rnd((M, K), 41), dtype)
+    W = q(rnd((N, K), 42, 1.0 / math.sqrt(K)), dtype)
+    dA, dW = A.to(dtype).cuda(), W.to(dtype).cuda()
+    A8, W8 = torch.zeros((M, K), dtype=torch.uint8, device="cuda"), torch.zeros((N, K), dtype=torch.uint8, device="cuda")
+    sa, sw = torch.zeros((M,), dtype=torch.float32, device="cuda"), torch.zeros((N,), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_quant_fp8(m._h, ptr(dA), M, K, ptr(A8), ptr(sa)))
+    chk(m._lib.svln_op_quant_fp8(m._h, ptr(dW), N, K, ptr(W8), ptr(sw)))
+    Ad = A8.view(torch.float8_e4m3fn).float().cpu() * sa.cpu()[:, None]
+    Wd = W8.view(torch.float8_e4m3fn).float().cpu() * sw.cpu()[:, None]
+    assert float((Ad - A).abs().max()) <= float(A.abs().max()) * 2.0 ** -4            # e4m3: 3 mantissa bits
+    exp = Ad @ Wd.t()
+    b = q(rnd((N,), 43, 0.1), dtype) if bias else None
+    r = q(rnd((M, N), 44), dtype) if res else None
+    if b is not None:
+        exp = exp + b
+    n_out = N
+    if epi == _lib.EPI_SWIGLU:
+        idx = torch.arange(N // 2)
+        exp = O.silu(exp[:, (idx // 32) * 64 + idx % 32]) * exp[:, (idx // 32) * 64 + 32 + idx % 32]
+        n_out = N // 2
+    if r is not None:
+        exp = exp + r
+    db = b.to(dtype).cuda() if bias else None
+    dr = r.to(dtype).cuda() if res else None
+    out = torch.zeros((M, n_out), dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    chk(m._lib.svln_op_gemm_fp8(m._h, ptr(A8), ptr(sa), K, ptr(W8), ptr(sw), K, ptr(out), n_out, ptr(db), ptr(dr), n_out, M, N, K, epi, *cfgsplit))
+    assert_close(out, exp, dtype, f"fp8 gemm {M}x{N}x{K} epi{epi} cfg{cfgsplit}")
+
+
 def test_gemv_fp8_swiglu_and_argmax():
     dtype = torch.bfloat16
     m = engine(TINY, dtype)
