@@ -371,7 +371,7 @@ def main():
             # configs[4] as BASELINE.json words it: batch of concurrent envs + fp8 MFMA on the QKV / MLP GEMMs (prefill rows and the
             # 32-row decode-step products of the batch); opt-in, reduced precision
             model.set_fp8_gemm(True)
-            while bstep[0] != EP_STEPS:
+            while bstep[0] <= EP_STEPS - NUM_FUTURE:        # finish the episode (after its last turn bstep == EP_STEPS - NUM_FUTURE + 1)
                 lockstep_turn()
             dt8 = timed_pass(model, lockstep_turn, a.steps, a.warmup, world)
             model.set_fp8_gemm(False)
