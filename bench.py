@@ -291,6 +291,22 @@ def main():
                     "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                     "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
 
+    roof2 = None
+    if not a.no_probe:
+        ms2, n2 = C.c_double(), C.c_int64()
+        rows2, fl2, wb2 = C.c_double(), C.c_double(), C.c_double()
+        lib.svln_probe_read_prefill(h, C.byref(ms2), C.byref(n2), C.byref(rows2), C.byref(fl2), C.byref(wb2))
+        if n2.value:
+            t2 = ms2.value / n2.value / 1e3
+            # the steady prefill's largest product sits between both roofs (intensity ~ 2 * rows flop/B ~ the ridge): report both
+            roof2 = {"bound": "mfma", "kernel": "gemm_glds_kernel<bf16, EPI_SWIGLU, 256x128 tiles> + K-split tail + reduce (prefill gate/up, layer 0 "
+                                               "of every steady turn, HIP events on the engine's stream)",
+                     "achieved": round(fl2.value / t2 / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl2.value / t2 / 2.5e15, 4),
+                     "traffic": None, "rows": round(rows2.value, 1), "flops_per_launch": fl2.value, "avg_us": round(t2 * 1e6, 2),
+                     "launches_timed": n2.value,
+                     "weight_stream": {"bound": "hbm", "achieved": round(wb2.value / t2 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(wb2.value / t2 / 8e12, 4), "bytes_per_launch": wb2.value}}
+
     def extra_pass(setup, teardown):
         setup()
         finish_episode()
@@ -408,6 +424,7 @@ def main():
                                   "ms_per_step": round((dt - pre_wall_s) / a.steps * 1e3, 3)},
             "metric_allreduce_check": summary,
             "roofline": roof,
+            "roofline_prefill_gemm": roof2,
             "with_feature_cache": cached,
             "fp8_decode_weights": fp8,
             "memory_prune_32": pruned,

@@ -123,6 +123,9 @@ int svln_set_fp8_gemm(svln_engine* h, int enable);
 int svln_set_memory_prune(svln_engine* h, int keep_tokens);
 int svln_probe_reset(svln_engine* h);
 int svln_probe_read(svln_engine* h, double* total_ms, int64_t* launches, double* bytes_per_launch);
+/* second probe armed by svln_probe_reset: the layer-0 gate/up product of every steady prefill (<= 256 rows) between two stream events:
+ * total ms, how many, their mean row count, flops of one (2 * rows * 2 * inter * hidden) and its weight bytes */
+int svln_probe_read_prefill(svln_engine* h, double* total_ms, int64_t* count, double* mean_rows, double* flops, double* weight_bytes);
 int svln_phase_times(svln_engine* h, double* vision_ms, double* prefill_ms, double* decode_ms, int reset);
 
 /* -- optional memoisation of pooled frame features keyed by a 128-bit content hash of the pixels:

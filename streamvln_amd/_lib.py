@@ -64,6 +64,7 @@ SIGNATURES = {
     "svln_op_memory_prune": (_I, [_P, _P, _I, _I, _PI32, _PF]),
     "svln_probe_reset": (_I, [_P]),
     "svln_probe_read": (_I, [_P, _PD, _PI64, _PD]),
+    "svln_probe_read_prefill": (_I, [_P, _PD, _PI64, _PD, _PD, _PD]),
     "svln_phase_times": (_I, [_P, _PD, _PD, _PD, _I]),
     "svln_set_feature_cache": (_I, [_P, _I]),
     "svln_feature_cache_stats": (_I, [_P, _PI64, _PI64]),

@@ -95,6 +95,7 @@ struct EngineBase {
     virtual void probe_reset() = 0;
     virtual void probe_read(double* ms, int64_t* launches, double* bytes) = 0;
     virtual void phase_times(double* v, double* p, double* d, int reset) = 0;
+    virtual void probe_read_prefill(double* ms, int64_t* n, double* rows, double* flops, double* wbytes) = 0;
     virtual void set_feature_cache(int cap) = 0;
     virtual void feature_cache_stats(int64_t* hits, int64_t* misses) = 0;
     virtual bool op_gemm(const GemmArgs& a) = 0;
@@ -170,6 +171,8 @@ public:
     bool use_graph = false;
     hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr}; int graph_env = -1;
     std::vector<hipEvent_t> probe_ev; size_t probe_used = 0; bool probe_on = false; double probe_bytes = 0;
+    // second probe: the layer-0 gate/up product of every steady prefill (M <= 256 rows: main launch + K-split tail + reduce) between two events
+    std::vector<hipEvent_t> pprobe_ev; size_t pprobe_used = 0; double pprobe_rows = 0;
     hipEvent_t ph_ev[5]; double ph_ms[3] = {0, 0, 0}; bool vision_pending = false;   // v0 v1 p0 p1 d1
 
     template <typename U> U* dalloc(size_t n, bool zero = false) {
@@ -353,6 +356,7 @@ public:
         for (int i = 0; i < 2; ++i) if (pp_ev[i]) (void)hipEventDestroy(pp_ev[i]);
         if (src_ev) (void)hipEventDestroy(src_ev);
         for (auto e : probe_ev) (void)hipEventDestroy(e);
+        for (auto e : pprobe_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
         (void)hipHostFree(h_ctl); (void)hipHostFree(h_out_ids);
         if (h_hash) (void)hipHostFree(h_hash);
@@ -740,7 +744,10 @@ public:
             GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE);
             ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
             if (!llm_gemm(ao, L.o8)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
+            const bool pp = i == 0 && probe_on && M <= 256 && n_dec == 0 && pprobe_used + 2 <= pprobe_ev.size();
+            if (pp) HIP_CHECK(hipEventRecord(pprobe_ev[pprobe_used], st));
             llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU), L.gu8);
+            if (pp) { HIP_CHECK(hipEventRecord(pprobe_ev[pprobe_used + 1], st)); pprobe_used += 2; pprobe_rows += M; }
             GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE);
             if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
             xn_ready = llm_gemm(ad, L.down8);
@@ -1269,7 +1276,8 @@ public:
     }
     void probe_reset() override {
         if (probe_ev.empty()) { probe_ev.resize(4096); for (auto& ev : probe_ev) HIP_CHECK(hipEventCreate(&ev)); }
-        probe_used = 0; probe_on = true;
+        if (pprobe_ev.empty()) { pprobe_ev.resize(512); for (auto& ev : pprobe_ev) HIP_CHECK(hipEventCreate(&ev)); }
+        probe_used = 0; probe_on = true; pprobe_used = 0; pprobe_rows = 0;
         probe_bytes = (double)2 * I * H * sizeof(T);
     }
     void probe_read(double* ms, int64_t* launches, double* bytes) override {
@@ -1278,6 +1286,15 @@ public:
         for (size_t k = 0; k + 1 < probe_used; k += 2) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, probe_ev[k], probe_ev[k + 1])); tot += t; }
         *ms = tot; *launches = (int64_t)(probe_used / 2); *bytes = probe_bytes;
         probe_on = false;
+    }
+    // steady-prefill gate/up products timed since probe_reset: total ms, count, mean rows, flops of one (2 * rows * 2I * H) and its weight bytes
+    void probe_read_prefill(double* ms, int64_t* n, double* rows, double* flops, double* wbytes) override {
+        HIP_CHECK(hipStreamSynchronize(st));
+        double tot = 0;
+        for (size_t k = 0; k + 1 < pprobe_used; k += 2) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, pprobe_ev[k], pprobe_ev[k + 1])); tot += t; }
+        const int64_t cnt = (int64_t)(pprobe_used / 2);
+        *ms = tot; *n = cnt; *rows = cnt ? pprobe_rows / cnt : 0;
+        *flops = 2.0 * (*rows) * 2.0 * I * H; *wbytes = (double)2 * I * H * sizeof(T);
     }
     void phase_times(double* v, double* p, double* d, int reset) override {
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1457,6 +1474,9 @@ int svln_op_memory_prune(svln_engine* h, const void* mem, int n_rows, int keep, 
 }
 int svln_probe_reset(svln_engine* h) { API_BEGIN_H h->impl->probe_reset(); API_END }
 int svln_probe_read(svln_engine* h, double* ms, int64_t* launches, double* bytes) { API_BEGIN_H h->impl->probe_read(ms, launches, bytes); API_END }
+int svln_probe_read_prefill(svln_engine* h, double* ms, int64_t* n, double* rows, double* flops, double* wbytes) {
+    API_BEGIN_H h->impl->probe_read_prefill(ms, n, rows, flops, wbytes); API_END
+}
 int svln_phase_times(svln_engine* h, double* v, double* p, double* d, int reset) { API_BEGIN_H h->impl->phase_times(v, p, d, reset); API_END }
 int svln_set_feature_cache(svln_engine* h, int capacity_frames) { API_BEGIN_H h->impl->set_feature_cache(capacity_frames); API_END }
 int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses) { API_BEGIN_H h->impl->feature_cache_stats(hits, misses); API_END }
