@@ -50,7 +50,7 @@ SVLN_DEV int v_off_f32(int row, int c) { return row * 256 + ((c ^ (row & 15)) <<
 SVLN_DEV int v_off_bf16(int row, int unit) { return row * 128 + ((unit ^ ((row >> 1) & 15)) << 3); }
 
 template <typename T, int HD, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1) void attn_kernel(AttnArgs p) {
     using G = AttnGeom<T, HD>;
     constexpr int NT = WAVES * 64;
     constexpr int EPC = G::EPC;
