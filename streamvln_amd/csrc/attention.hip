@@ -19,6 +19,8 @@
 // Roofline: decode = HBM (KV bytes 2*nkv*hd*len*sizeof(T) per layer); prefill/ViT = MFMA by flops, but at these sizes
 // (<= 1.2 waves per SIMD) measured ~3 us of exposed latency per 64-key tile: the softmax VALU work, the MFMA chains and the
 // LDS round trips of a wave serialise.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -33,21 +35,34 @@ template <typename T, int HD> struct AttnGeom {
     static constexpr int DT = (HD + 31) / 32;                          // 32-row output tiles along d
     static constexpr int VROWS = DT * 32;
     static constexpr int VC = 64 / EPC;                                // chunks per Vt row (64 keys)
-    static constexpr int K_TILE_BYTES = 64 * HDC * 16;
-    static constexpr int V_TILE_BYTES = VROWS * VC * 16;
     static constexpr bool KSWZ = (HDC % 16) == 0;
+    // LDS row of the K tile: 256-byte rows (head dim 128) are XOR-swizzled; other widths (head dim 72: 160 / 288 B) get one chunk of
+    // padding instead, which makes the bank stride of consecutive rows 44 (bf16) / 76 (fp32) dwords: 16 rows -> 16 distinct 16-byte slots
+    static constexpr int KROW = (KSWZ ? HDC : HDC + 1) * 16;
+    static constexpr int K_TILE_BYTES = 64 * KROW;
+    static constexpr int V_TILE_BYTES = VROWS * VC * 16;
 };
 
 SVLN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32
 
 // K tile: chunk c of key row `row`
 template <typename G> SVLN_DEV int k_off(int row, int c) {
-    return row * (G::HDC * 16) + ((G::KSWZ ? (c ^ (row & 15)) : c) << 4);
+    return row * G::KROW + ((G::KSWZ ? (c ^ (row & 15)) : c) << 4);
 }
 // Vt tile, float: 16 chunks (256 B) per row, ds_read_b128 -> XOR chunk with row & 15
 SVLN_DEV int v_off_f32(int row, int c) { return row * 256 + ((c ^ (row & 15)) << 4); }
 // Vt tile, bf16: 16 units of 8 B (128 B) per row, ds_read_b64 by 32-lane halves -> XOR unit with (row>>1)&15
 SVLN_DEV int v_off_bf16(int row, int unit) { return row * 128 + ((unit ^ ((row >> 1) & 15)) << 3); }
+
+// 8-byte LDS read as inline asm: left to itself hipcc pairs the Vt fragment reads of two output tiles into ds_read2st64_b64, which is
+// banked modulo 32 in 16-lane groups (and moves half the bytes per LDS cycle): under that mapping the Vt swizzle below, built for
+// ds_read_b64's 64 banks / 32-lane halves, is 2-way conflicted (measured: SQ_LDS_BANK_CONFLICT = 38-43 % of SQ_LDS_IDX_ACTIVE).
+template <int OFF> SVLN_DEV void lds_read_b64(uint2& v, unsigned addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); }
+template <int N> SVLN_DEV void lds_wait(uint2& a, uint2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+// compile-time loop with the index as a constant (immediate offsets / counted waits in inline asm)
+template <int I, int N, typename F> SVLN_DEV void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 template <typename T, int HD, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1) void attn_kernel(AttnArgs p) {
@@ -260,20 +275,29 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
 
         // ---- O^T += Vt_tile . P^T   (A = Vt rows (d), B = P from the S accumulators of this lane)
         if (sizeof(T) == 2) {
+            // row d*32 + r of the Vt tile: (row >> 1) & 15 does not depend on d, so the DT fragment pairs of a k-step share two address
+            // registers (lo / hi unit) and differ by an immediate offset of 32 rows = 4 KiB
+            const unsigned sv0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sV + r * 128;
+            const int xr = (r >> 1) & 15;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int j = ks >> 1, b0 = 8 * (ks & 1);
+                const unsigned alo = sv0 + (((4 * ks + h) ^ xr) << 3), ahi = sv0 + (((4 * ks + 2 + h) ^ xr) << 3);
+                uint2 vlo[G::DT], vhi[G::DT];
+                static_for<0, G::DT>([&](auto dc) {
+                    constexpr int d = decltype(dc)::value;
+                    lds_read_b64<d * 4096>(vlo[d], alo);
+                    lds_read_b64<d * 4096>(vhi[d], ahi);
+                });
                 // element jj of lane half h  <->  key 16*ks + 8*(jj>>2) + 4*h + (jj&3)   (regs b0 .. b0+7)
                 const uint4 pf = make_uint4(pack_bf16x2(S[j][b0 + 0], S[j][b0 + 1]), pack_bf16x2(S[j][b0 + 2], S[j][b0 + 3]),
                                             pack_bf16x2(S[j][b0 + 4], S[j][b0 + 5]), pack_bf16x2(S[j][b0 + 6], S[j][b0 + 7]));
-#pragma unroll
-                for (int d = 0; d < G::DT; ++d) {
-                    const int row = d * 32 + r;
-                    const uint2 lo = *(const uint2*)(sV + v_off_bf16(row, 4 * ks + h));
-                    const uint2 hi = *(const uint2*)(sV + v_off_bf16(row, 4 * ks + 2 + h));
-                    O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)),
+                static_for<0, G::DT>([&](auto dc) {
+                    constexpr int d = decltype(dc)::value;
+                    lds_wait<2 * (G::DT - 1 - d)>(vlo[d], vhi[d]);          // LDS reads return in order: only younger pairs remain
+                    O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(vlo[d].x, vlo[d].y, vhi[d].x, vhi[d].y)),
                                                                    __builtin_bit_cast(bf16x8, pf), O[d], 0, 0, 0);
-                }
+                });
             }
         } else {
 #pragma unroll

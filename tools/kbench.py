@@ -45,6 +45,27 @@ def main():
             for i in range(reps):
                 W = Ws[i % nw]
                 _lib.check(lib.svln_op_gemm(h, ptr(A), K, ptr(W), K, ptr(out), Cn, None, None, 0, 0, M, N, K, epi, fc, fs))
+    elif what == "attn":
+        # ViT attention on one frame (true dims) and LLM prefill attention T=212 over a 1700-key context (true dims, 1 layer)
+        from streamvln_amd.config import TRUE1
+        m.close()
+        m = StreamVLNForCausalLM(TRUE1, dtype=torch.bfloat16, max_envs=1, max_frames=9, max_positions=4096)
+        lib, h = m._lib, m._h
+        cfg = TRUE1
+        F = int(os.environ.get("KBENCH_FRAMES", "1"))
+        qkv = (torch.rand(F * 729, 3 * cfg.v_hidden, device="cuda") - 0.5).to(dt)
+        out = torch.zeros(F * 729, cfg.v_hidden, device="cuda", dtype=dt)
+        torch.cuda.synchronize()
+        for i in range(reps):
+            _lib.check(lib.svln_op_attention_vit(h, ptr(qkv), 3 * cfg.v_hidden, F, ptr(out), cfg.v_hidden))
+        T, P = int(os.environ.get("KBENCH_T", "212")), int(os.environ.get("KBENCH_P", "1700"))
+        qd = (cfg.q_heads + 2 * cfg.kv_heads) * 128
+        ctx = (torch.rand(P, qd, device="cuda") - 0.5).to(dt)
+        new = (torch.rand(T, qd, device="cuda") - 0.5).to(dt)
+        o2 = torch.zeros(T, cfg.q_heads * 128, device="cuda", dtype=dt)
+        torch.cuda.synchronize()
+        for i in range(reps):
+            _lib.check(lib.svln_op_attention_llm(h, ptr(new.clone()), qd, T, P, ptr(ctx.clone()), P, ptr(o2), cfg.q_heads * 128, 1))
     elif what == "gemv":
         for (N, K, norm, epi) in [(37888, 3584, True, _lib.EPI_SWIGLU), (4608, 3584, True, 0), (3584, 3584, False, 0),
                                   (3584, 18944, False, 0), (152064, 3584, False, _lib.EPI_ARGMAX)]:
