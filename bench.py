@@ -284,7 +284,7 @@ def main():
             avg_s = ms.value / n.value / 1e3
             ach = by.value / avg_s / 1e9
             traffic = None          # HBM bytes/launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
-            pmc = os.path.join(ROOT, "profiles", "r01_gemv_swiglu_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_gemv_swiglu_pmc.json")
             if os.path.exists(pmc) and a.config == "streamvln_qwen2_7b" and a.dtype == "bf16":
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)", "achieved": round(ach, 1),
