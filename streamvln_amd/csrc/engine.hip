@@ -610,6 +610,7 @@ public:
             for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreate(&pp_ev[i]));
         }
         const ResampleDev& tabs = resample_tabs(Hh, Ww);
+        REQUIRE(tabs.ks_v <= 40, "frame too large for the GPU preprocess kernel (more than 40 source rows per output row)");
         REQUIRE(preprocess_lds_bytes(Ww, Sx, tabs.ks_v) <= (size_t)160 * 1024,
                 "frame too large for the GPU preprocess kernel (its source rows of one output row must fit the 160 KiB LDS)");
         if (d_rgb_cap < bytes + 64) {

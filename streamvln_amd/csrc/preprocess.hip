@@ -27,6 +27,7 @@ SVLN_DEV int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+template <int MAX_V>
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, const int* __restrict__ hmin,
                                                          const int* __restrict__ hcnt, const int* __restrict__ hk, int ks_h,
                                                          const int* __restrict__ vmin, const int* __restrict__ vcnt, const int* __restrict__ vk,
@@ -45,16 +46,25 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     const int nchunks = (shift + cnt * rowb + 15) >> 4;
     for (int i = tid; i < nchunks; i += 256) smem[i] = *(const uint4*)(rgb + a0 + (size_t)i * 16);
     __syncthreads();
-    // ---- horizontal pass (ImagingResampleHorizontal_8bpc)
-    for (int idx = tid; idx < cnt * S3; idx += 256) {
-        const int r = idx / S3, j = idx - r * S3;
+    // ---- horizontal pass (ImagingResampleHorizontal_8bpc): a thread owns output bytes j = tid, tid + 256, ... of EVERY staged row, so
+    // the byte's column, channel, window and weights are set up once and reused for the <= ks_v rows
+    for (int j = tid; j < S3; j += 256) {
         const int xx = j / 3, c = j - 3 * xx;
-        const uint8_t* px = s_rows + shift + r * rowb + hmin[xx] * 3 + c;
+        const uint8_t* px = s_rows + shift + hmin[xx] * 3 + c;
         const int* k = hk + xx * ks_h;
         const int n = hcnt[xx];
-        int acc = 1 << (PRECISION_BITS - 1);
-        for (int t = 0; t < n; ++t) acc += (int)px[3 * t] * k[t];
-        s_hor[idx] = (uint8_t)clip8(acc);
+        int acc[MAX_V];
+#pragma unroll
+        for (int r = 0; r < MAX_V; ++r) acc[r] = 1 << (PRECISION_BITS - 1);
+        for (int t = 0; t < n; ++t) {
+            const int kt = k[t];
+#pragma unroll
+            for (int r = 0; r < MAX_V; ++r)
+                if (r < cnt) acc[r] += (int)px[r * rowb + 3 * t] * kt;
+        }
+#pragma unroll
+        for (int r = 0; r < MAX_V; ++r)
+            if (r < cnt) s_hor[r * S3 + j] = (uint8_t)clip8(acc[r]);
     }
     __syncthreads();
     // ---- vertical pass (ImagingResampleVertical_8bpc) + rescale / normalise table, channel-planar
@@ -130,12 +140,22 @@ size_t preprocess_lds_bytes(int W, int S, int ks_v) {
 void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_frames, int H, int W, int S, const ResampleDev& t, const float* lut) {
     const int rows_cap = (int)((((size_t)t.ks_v * 3 * W + 15 + 15) & ~(size_t)15) + 16);
     const size_t lds = preprocess_lds_bytes(W, S, t.ks_v);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(S, n_frames), dim3(256), lds, s, rgb, out, t.hmin, t.hcnt, t.hk, t.ks_h, t.vmin, t.vcnt, t.vk, t.ks_v,
-                       lut, H, W, S, rows_cap);
+    // the vertical window (ks_v source rows per output row) is a compile-time bound of the per-thread accumulators
+    if (t.ks_v <= 8)
+        hipLaunchKernelGGL(preprocess_kernel<8>, dim3(S, n_frames), dim3(256), lds, s, rgb, out, t.hmin, t.hcnt, t.hk, t.ks_h, t.vmin, t.vcnt, t.vk, t.ks_v,
+                           lut, H, W, S, rows_cap);
+    else if (t.ks_v <= 16)
+        hipLaunchKernelGGL(preprocess_kernel<16>, dim3(S, n_frames), dim3(256), lds, s, rgb, out, t.hmin, t.hcnt, t.hk, t.ks_h, t.vmin, t.vcnt, t.vk, t.ks_v,
+                           lut, H, W, S, rows_cap);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<40>, dim3(S, n_frames), dim3(256), lds, s, rgb, out, t.hmin, t.hcnt, t.hk, t.ks_h, t.vmin, t.vcnt, t.vk, t.ks_v,
+                           lut, H, W, S, rows_cap);
 }
 
 void preprocess_init_attrs() {
-    (void)hipFuncSetAttribute((const void*)preprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)preprocess_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)preprocess_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)preprocess_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace svln
