@@ -444,7 +444,7 @@ public:
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
         a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
-        a.a_scale = nullptr; a.w_scale = nullptr; return a;
+        a.a_scale = nullptr; a.w_scale = nullptr; a.rope = nullptr; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -726,7 +726,12 @@ public:
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
-            llm_gemm(gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE), L.qkv8);
+            // one env's turn alone in the batch: the QKV product's split-K reduce also applies RoPE and appends k / v to its pages
+            RopeKvArgs r0; r0.qkv = qkv; r0.ld = qkv_dim; r0.Kpool = L.kpool; r0.Vpool = L.vpool; r0.rope_tab = rope_tab;
+            r0.nq = nq; r0.nkv = nkv; r0.dyn_pos = nullptr;
+            GemmArgs aq = gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE);
+            if (segs.size() == 1 && n_dec == 0) { r0.page_table = segs[0].e->d_pages; r0.T = segs[0].Tn; r0.P = segs[0].P; aq.rope = &r0; }
+            const bool roped = llm_gemm(aq, L.qkv8);
             if (n_dec > 0) {
                 AttnArgs a = batched_decode_attn_args(L, n_dec);
                 launch_attention<T>(st, a, 128, 1);
@@ -734,9 +739,9 @@ public:
             }
             for (const Seg& g : segs) {
                 T* q_g = qkv + (size_t)g.off * qkv_dim;
-                RopeKvArgs r; r.qkv = q_g; r.ld = qkv_dim; r.Kpool = L.kpool; r.Vpool = L.vpool; r.page_table = g.e->d_pages; r.rope_tab = rope_tab;
-                r.T = g.Tn; r.nq = nq; r.nkv = nkv; r.P = g.P; r.dyn_pos = nullptr;
-                launch_rope_kv<T>(st, r);
+                RopeKvArgs r = r0; r.qkv = q_g; r.page_table = g.e->d_pages;
+                r.T = g.Tn; r.P = g.P;
+                if (!roped) launch_rope_kv<T>(st, r);
                 AttnArgs a = llm_attn_args(L, *g.e, q_g, qkv_dim, attn + (size_t)g.off * qd, qd, g.Tn, g.P, g.P + g.Tn, false);
                 launch_attention<T>(st, a, 128, 4);
                 if (a.nsplit > 1) launch_attention_combine<T>(st, a, 128);

@@ -623,6 +623,42 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
     }
 }
 
+// Split-K reduce of the prefill QKV product fused with its tail (modeling_qwen2.py:195-235): C = round(sum_s slab + bias), RoPE on the
+// q and k heads (cos / sin table, rotate_half), q back into C, roped k and v^T appended to the paged KV cache -- splitk_epilogue_kernel
+// followed by rope_kv_kernel in one pass (same arithmetic, same intermediate rounding to T).  grid (rows, nq + 2 nkv heads), 64 threads:
+// lane d owns columns d and d + 64 of a 128-wide head.
+template <typename T>
+__global__ __launch_bounds__(64) void splitk_qkv_rope_kernel(GemmArgs p, RopeKvArgs r) {
+    const int i = blockIdx.x, hd = blockIdx.y, d = threadIdx.x;
+    const size_t slab = (size_t)p.M * p.N;
+    const int c0 = hd * 128 + d;
+    const float* src = p.ws + (size_t)i * p.N + c0;
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int s = 0; s < p.nsplit; ++s) { a1 += src[s * slab]; a2 += src[s * slab + 64]; }
+    const T* bias = (const T*)p.bias;
+    if (bias) { a1 += to_f32(bias[c0]); a2 += to_f32(bias[c0 + 64]); }
+    const float x1 = to_f32(from_f32<T>(a1)), x2 = to_f32(from_f32<T>(a2));      // the unfused path stores C in T before the rotation
+    const int pos = (r.dyn_pos ? *r.dyn_pos : r.P) + i;
+    const int page = r.page_table[pos >> 6], off = pos & 63;
+    T* row = (T*)p.C + (size_t)i * p.ldc + (size_t)hd * 128;
+    if (hd < r.nq + r.nkv) {
+        const float c = r.rope_tab[(size_t)pos * 128 + d], sn = r.rope_tab[(size_t)pos * 128 + 64 + d];
+        const float o1 = x1 * c - x2 * sn, o2 = x2 * c + x1 * sn;
+        if (hd < r.nq) {
+            row[d] = from_f32<T>(o1);
+            row[d + 64] = from_f32<T>(o2);
+        } else {
+            T* kr = (T*)r.Kpool + (((size_t)page * r.nkv + (hd - r.nq)) * 64 + off) * 128;
+            kr[d] = from_f32<T>(o1);
+            kr[d + 64] = from_f32<T>(o2);
+        }
+    } else {
+        T* vt = (T*)r.Vpool + ((size_t)page * r.nkv + (hd - r.nq - r.nkv)) * 128 * 64;
+        vt[(size_t)d * 64 + off] = from_f32<T>(x1);
+        vt[(size_t)(d + 64) * 64 + off] = from_f32<T>(x2);
+    }
+}
+
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
@@ -647,6 +683,10 @@ template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_
     launch_cfg<T, EPI, C, true>(s, a, S);
     if (EPI == EPI_NONE && a.norm_out && a.norm_w && a.tile_base == 0 && a.N <= 4096 && a.N % 4 == 0) {
         hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(((a.N / 4 + 63) / 64) * 64), 0, s, a);
+        return true;
+    }
+    if (EPI == EPI_NONE && a.rope && a.tile_base == 0 && !a.res && a.N == (a.rope->nq + 2 * a.rope->nkv) * 128 && a.M == a.rope->T) {
+        hipLaunchKernelGGL((splitk_qkv_rope_kernel<T>), dim3(a.M, a.N / 128), dim3(64), 0, s, a, *a.rope);
         return true;
     }
     const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;

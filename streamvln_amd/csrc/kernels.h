@@ -11,6 +11,7 @@ namespace svln {
 
 enum Epi : int { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4 };
 
+struct RopeKvArgs;
 // C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]) + res[row % res_mod or row][N]      (all T, fp32 accumulate)
 // K, lda, ldw multiples of one 16-byte chunk; EPI_SWIGLU: W rows are 32-row blocks
 // [gate 32 | up 32] and C is [M, N/2] = silu(gate) * up.
@@ -29,6 +30,10 @@ struct GemmArgs {
     // when the product takes the split-K path with N <= 4096 the slab reduce also writes norm_out = rmsnorm(C) * norm_w and
     // launch_gemm returns true; otherwise norm_out is untouched (false) and the caller runs launch_rmsnorm itself
     const void* norm_w; void* norm_out; float norm_eps;
+    // optional fused tail of the QKV product of a prefill (Qwen2Attention: bias, RoPE on q / k, KV append): when the product takes the
+    // split-K path the slab reduce also applies RoPE and appends k / v^T to the paged cache (rope->qkv must be C) and launch_gemm
+    // returns true; otherwise C holds the plain product + bias and the caller runs launch_rope_kv itself
+    const RopeKvArgs* rope;
     const void* norm_b;           // non-null: LayerNorm (mean/variance, weight norm_w, bias norm_b) instead of RMSNorm -- the ViT's ln1 / ln2
     // opt-in fp8 (OCP e4m3) operands (bf16 engine): when a_scale is set, A [M][K] and W [N][K] are e4m3 bytes (lda / ldw in
     // elements), C = a_scale[m] * w_scale[n] * (A . W^T) then the usual epilogue in bf16; K % 16 == 0

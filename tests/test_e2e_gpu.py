@@ -253,22 +253,23 @@ def test_fp8_mfma_gemms_opt_in():
             break
     assert worst < 0.10 and agree >= 1, (worst, agree, total)
     print(f"fp8 MFMA GEMMs: {agree}/{total} token ids agree with bf16 before the first divergence, hidden rel err {worst:.4f}")
-    # 4 envs through generate_batch: the batched decode steps take the 32-row fp8 MFMA path; per-env results = the solo fp8 runs' first turn
+    # 8 envs through generate_batch: prefill rows and the batched decode steps (32-row tiles) take the fp8 MFMA path
     m.close()
-    m = StreamVLNForCausalLM(sc["cfg"], dtype=torch.bfloat16, max_envs=4, max_frames=4, max_positions=1024)
+    NE = 8                                                   # configs[4]: 8 concurrent envs + fp8 MFMA products
+    m = StreamVLNForCausalLM(sc["cfg"], dtype=torch.bfloat16, max_envs=NE, max_frames=NE, max_positions=1024)
     m.load_synthetic(SEED)
     m.model.num_history = 2
     m.set_fp8_gemm(True)
     reqs = []
-    for e in range(4):
+    for e in range(NE):
         ids, img = _first_turn_inputs(m, sc, step=e, seed=20 + e)
         reqs.append(dict(inputs=ids, images=img, env_id=e, time_ids=[[0]]))
     outs = m.generate_batch(reqs, max_new_tokens=4, eos_token_ids=[])
-    hb = [m.last_hidden_batch(e) for e in range(4)]
+    hb = [m.last_hidden_batch(e) for e in range(NE)]
     m.set_fp8_gemm(False)
-    m.reset(4)
+    m.reset(NE)
     outs16 = m.generate_batch(reqs, max_new_tokens=4, eos_token_ids=[])
-    for e in range(4):
+    for e in range(NE):
         h16 = m.last_hidden_batch(e)
         assert outs[e].sequences.shape == (1, 4)
         rel = float(np.linalg.norm(hb[e][0] - h16[0]) / np.linalg.norm(h16[0]))      # first token: prefill only
@@ -536,6 +537,36 @@ def test_memory_prune_extension_vs_live_oracle():
         if a["memory"]:
             n_a, n_f = len(a["out"].sequences[0]), len(f["out"].sequences[0])
             assert f["out"].past_key_values.get_seq_length() - n_f == a["out"].past_key_values.get_seq_length() - n_a + 2 * 196 - keep
+    m.close()
+
+
+def test_config3_long_window_with_pruned_memory_vs_live_oracle():
+    """BASELINE configs[3] in one piece ("64-step horizon, 16-frame window, 32-token pruned slow memory") on the TINY model: num_frames 64
+    (a 16-turn window), num_history 8, `<memory>` pruned to 32 tokens, 72 env steps = the full first window (KV to ~3.4k positions), the
+    window restart at step 64 (9 views, 8 x 196 memory tokens pruned to 32) and one turn after it.  fp32 engine vs the CPU oracle run live
+    with the same extension (the prune rule has no reference counterpart): ids identical, hidden <= 1e-3, cache lengths equal."""
+    from oracle import streamvln_oracle as O
+    from streamvln_amd import weights as W
+    from scenarios import run_scenario
+    sc = dict(SCENARIOS["tiny_episode"], steps=72, num_frames=64, num_history=8, max_new=5, eos_mod=0, lens=(40, 48, 16))
+    cfg, keep = sc["cfg"], 32
+    m = StreamVLNForCausalLM(cfg, dtype=torch.float32, max_envs=1, max_frames=9, max_positions=4096)
+    m.load_synthetic(SEED)
+    m.model.num_history = 8
+    m.set_memory_prune(keep)
+    hid = []
+    pre = m.get_vision_tower().image_processor.preprocess_array
+    log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
+    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=8, memory_keep=keep)
+    log_o = run_scenario(orc, sc, preprocess=pre)
+    assert len(log_g) == len(log_o) == 18
+    for t, (a, b) in enumerate(zip(log_g, log_o)):
+        assert a["out"].sequences[0].tolist() == b["out"].sequences[0].tolist(), t
+        assert np.abs(hid[t] - b["out"].hidden.numpy()).max() <= HIDDEN_TOL, t
+        assert a["out"].past_key_values.get_seq_length() == b["out"].cache_len, t
+    restart = log_g[16]
+    assert restart["memory"] and restart["views"] == 9 and restart["step_id"] == 64
+    assert restart["out"].past_key_values.get_seq_length() == (48 - 2) + keep + 196 + 5 - 1        # 46 text + 32 pruned memory + 196 image rows
     m.close()
 
 
