@@ -235,19 +235,26 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
             }
         }
 
-        // ---- mask, online softmax (per lane = per query row; other half of the keys is in lane ^ 32)
+        // ---- mask, online softmax (per lane = per query row; other half of the keys is in lane ^ 32).  Scores stay RAW in S: the
+        // scale (log2 domain) is folded into one fma per element, exp2(S * scale2 - m).  Only a tile that reaches past kv_len or past
+        // the causal diagonal of some row of this WORKGROUP is masked (uniform test); O is rescaled only when some lane's max moved.
+        const int tile_last_key = kt * 64 + 63;
+        const bool need_mask = tile_last_key >= kv_len || (p.causal && tile_last_key > P + (int)(blockIdx.x * WAVES * 32) / p.G);
+        if (need_mask) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 64 + j * 32 + acc_row(e, lane);
+                    if (!(key < kv_len && (!p.causal || key <= qpos))) S[j][e] = -INFINITY;
+                }
+        }
         float mloc = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * 64 + j * 32 + acc_row(e, lane);
-                const bool ok = key < kv_len && (!p.causal || key <= qpos);
-                const float sv = ok ? S[j][e] * scale2 : -INFINITY;        // log2 domain: softmax via v_exp_f32 (2^x)
-                S[j][e] = sv;
-                mloc = fmaxf(mloc, sv);
-            }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, S[j][e]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * scale2;             // scale2 > 0: max commutes with the scaling
         const float mnew = fmaxf(m, mloc);
         float alpha = 1.0f, psum = 0.0f;
         if (mnew == -INFINITY) {
@@ -261,17 +268,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = fast_exp2(S[j][e] - mnew);
+                    const float pv = fast_exp2(fmaf(S[j][e], scale2, -mnew));       // masked: -inf -> 0
                     S[j][e] = pv;
                     psum += pv;
                 }
         }
         l = l * alpha + psum;
         m = mnew;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int d = 0; d < G::DT; ++d)
+            for (int d = 0; d < G::DT; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
+                for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
+        }
 
         // ---- O^T += Vt_tile . P^T   (A = Vt rows (d), B = P from the S accumulators of this lane)
         if (sizeof(T) == 2) {
