@@ -26,6 +26,10 @@ def main():
     lib, h = m._lib, m._h
     dt = torch.bfloat16
     if what == "gemm":
+        from streamvln_amd.config import TRUE1
+        m.close()       # true-width engine: its split-K workspace holds the slabs of the true-width products
+        m = StreamVLNForCausalLM(TRUE1, dtype=torch.bfloat16, max_envs=1, max_frames=9, max_positions=4096)
+        lib, h = m._lib, m._h
         # (M, N, K, epi, force_cfg, force_split)  -- steady prefill and ViT shapes
         shapes = [(212, 37888, 3584, _lib.EPI_SWIGLU, 0, 0), (212, 4608, 3584, 0, 0, 0), (212, 3584, 3584, 0, 0, 0),
                   (212, 3584, 18944, 0, 0, 0), (729, 3456, 1152, 0, 0, 0), (729, 1152, 1152, 0, 0, 0),
