@@ -607,11 +607,10 @@ template <typename T> void launch_attention_combine(hipStream_t s, const AttnArg
 }
 template <typename T, int HD, int WAVES> static void attn_attr() {
     using G = AttnGeom<T, HD>;
-    (void)hipFuncSetAttribute((const void*)attn_kernel<T, HD, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              G::K_TILE_BYTES + G::V_TILE_BYTES);
+    set_max_lds((const void*)attn_kernel<T, HD, WAVES>, G::K_TILE_BYTES + G::V_TILE_BYTES);
 }
 void attention_init_attrs() {
-    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, AttnGeom<float, 128>::K_TILE_BYTES + AttnGeom<float, 128>::V_TILE_BYTES);
+    set_max_lds((const void*)attn_decode_kernel<float>, AttnGeom<float, 128>::K_TILE_BYTES + AttnGeom<float, 128>::V_TILE_BYTES);
     attn_attr<bf16, 128, 1>(); attn_attr<bf16, 128, 4>(); attn_attr<bf16, 72, 1>(); attn_attr<bf16, 72, 4>();
     attn_attr<float, 128, 1>(); attn_attr<float, 128, 4>(); attn_attr<float, 72, 1>(); attn_attr<float, 72, 4>();
 }

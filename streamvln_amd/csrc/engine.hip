@@ -341,7 +341,7 @@ public:
         }
         for (int p = pages_total - 1; p >= 0; --p) free_pages.push_back(p);
         for (int i = 0; i < 5; ++i) HIP_CHECK(hipEventCreate(&ph_ev[i]));
-        init_kernel_attributes();
+        HIP_CHECK(init_kernel_attributes());
         HIP_CHECK(hipStreamSynchronize(st));
     }
 

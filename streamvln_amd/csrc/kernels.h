@@ -197,10 +197,20 @@ size_t preprocess_lds_bytes(int W, int S, int ks_v);
 void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_frames, int H, int W, int S, const ResampleDev& t, const float* lut);
 void preprocess_init_attrs();
 
-// raise the dynamic-LDS limit of the kernels that may ask for more than 64 KiB (call once, outside capture)
+// raise the dynamic-LDS limit of the kernels that may ask for more than 64 KiB (call once, outside capture).  A refused attribute would
+// only show up later as a failed launch of that one kernel: the first refusal is kept and returned by init_kernel_attributes().
+inline hipError_t& attr_status() { static hipError_t e = hipSuccess; return e; }
+inline void set_max_lds(const void* fn, int bytes) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess && attr_status() == hipSuccess) attr_status() = e;
+}
 void gemm_init_attrs();
 void gemv_init_attrs();
 void attention_init_attrs();
-inline void init_kernel_attributes() { gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); preprocess_init_attrs(); }
+inline hipError_t init_kernel_attributes() {
+    attr_status() = hipSuccess;
+    gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); preprocess_init_attrs();
+    return attr_status();
+}
 
 }  // namespace svln

@@ -153,9 +153,9 @@ void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_fram
 }
 
 void preprocess_init_attrs() {
-    (void)hipFuncSetAttribute((const void*)preprocess_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)preprocess_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)preprocess_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set_max_lds((const void*)preprocess_kernel<8>, 160 * 1024);
+    set_max_lds((const void*)preprocess_kernel<16>, 160 * 1024);
+    set_max_lds((const void*)preprocess_kernel<40>, 160 * 1024);
 }
 
 }  // namespace svln
