@@ -63,6 +63,11 @@ int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on
  * (device).  Bit-exact with Pillow's two-pass fixed-point resampler (pillow==11.2.1, requirements.txt:97); complete on return.
  * svln_preprocess_time: accumulated GPU time (upload + kernel, HIP events) and frame count since the last reset. */
 int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev);
+/* The same work without the final wait: returns once the frame bytes have been consumed (copied to pinned staging) and the upload +
+ * kernel are enqueued on the engine's stream.  svln_encode_frames / svln_generate on the same engine are ordered behind it; any other
+ * stream that touches out_dev must first wait on the engine's stream (svln_engine_stream: the hipStream_t as a void*). */
+int svln_preprocess_frames_enqueue(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev);
+int svln_engine_stream(svln_engine* h, void** stream);
 int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset);
 
 /* -- splice: prepare_inputs_labels_for_multimodal (stream_video_vln.py:182-238) for one env.

@@ -43,6 +43,8 @@ SIGNATURES = {
     "svln_env_state": (_I, [_P, _I, _PI32, _PI32]),
     "svln_encode_frames": (_I, [_P, _P, _I, _I]),
     "svln_preprocess_frames": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "svln_preprocess_frames_enqueue": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "svln_engine_stream": (_I, [_P, C.POINTER(C.c_void_p)]),
     "svln_preprocess_time": (_I, [_P, _PD, _PI64, _I]),
     "svln_append_turn": (_I, [_P, _I, _PI64, _I, _I]),
     "svln_append_turn_at": (_I, [_P, _I, _PI64, _I, _I, _I]),

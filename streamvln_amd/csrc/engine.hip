@@ -71,7 +71,8 @@ struct EngineBase {
     virtual void kv_reset(int env) = 0;
     virtual void env_state(int env, int32_t* n_embeds, int32_t* kv_len) = 0;
     virtual void encode_frames(const float* pixels, int F, int on_device) = 0;
-    virtual void preprocess_frames(const uint8_t* rgb, int n, int height, int width, int on_device, float* out_dev) = 0;
+    virtual void preprocess_frames(const uint8_t* rgb, int n, int height, int width, int on_device, float* out_dev, bool wait) = 0;
+    virtual void* stream_handle() = 0;
     virtual void preprocess_time(double* ms, int64_t* frames, int reset) = 0;
     virtual int device_id() const = 0;
     virtual void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) = 0;
@@ -352,8 +353,11 @@ public:
         (void)hipStreamSynchronize(st);
         drop_graphs();
         if (d_rgb) (void)hipFree(d_rgb);
-        if (h_rgb) (void)hipHostFree(h_rgb);
-        for (int i = 0; i < 2; ++i) if (pp_ev[i]) (void)hipEventDestroy(pp_ev[i]);
+        for (int i = 0; i < 2; ++i) {
+            if (h_rgb[i]) (void)hipHostFree(h_rgb[i]);
+            if (h2d_ev[i]) (void)hipEventDestroy(h2d_ev[i]);
+        }
+        for (auto& pr : pp_pairs) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
         if (src_ev) (void)hipEventDestroy(src_ev);
         for (auto e : probe_ev) (void)hipEventDestroy(e);
         for (auto e : pprobe_ev) (void)hipEventDestroy(e);
@@ -576,8 +580,23 @@ public:
     // are built on the host per frame geometry (double precision, Pillow's operation order) and cached on the device.
     struct ResampleTabs { int H, W; ResampleDev dev; };
     std::vector<ResampleTabs> rs_tabs;
-    uint8_t* d_rgb = nullptr; size_t d_rgb_cap = 0; uint8_t* h_rgb = nullptr; size_t h_rgb_cap = 0; float* d_lut = nullptr;
-    hipEvent_t pp_ev[2] = {nullptr, nullptr}; double pp_ms = 0; int64_t pp_frames = 0;
+    uint8_t* d_rgb = nullptr; size_t d_rgb_cap = 0; float* d_lut = nullptr;
+    // pinned staging, double-buffered: call i + 1 copies its frame in while the DMA of call i may still be reading the other buffer
+    uint8_t* h_rgb[2] = {nullptr, nullptr}; size_t h_rgb_cap[2] = {0, 0}; hipEvent_t h2d_ev[2] = {nullptr, nullptr}; int h_cur = 0;
+    // GPU time of the preprocess calls: (begin, end) event pairs, read back lazily so that an enqueue-only call never waits
+    struct EvPair { hipEvent_t a, b; int frames; };
+    std::vector<EvPair> pp_pairs; size_t pp_pending = 0;
+    double pp_ms = 0; int64_t pp_frames = 0;
+    void pp_collect() {
+        for (size_t i = 0; i < pp_pending; ++i) {
+            float t = 0.f;
+            HIP_CHECK(hipEventSynchronize(pp_pairs[i].b));
+            HIP_CHECK(hipEventElapsedTime(&t, pp_pairs[i].a, pp_pairs[i].b));
+            pp_ms += t; pp_frames += pp_pairs[i].frames;
+        }
+        pp_pending = 0;
+    }
+    void* stream_handle() override { return (void*)st; }
     const ResampleDev& resample_tabs(int Hh, int Ww) {
         for (auto& t : rs_tabs) if (t.H == Hh && t.W == Ww) return t.dev;
         const int Sx = c.v_image;
@@ -596,7 +615,7 @@ public:
         rs_tabs.push_back(t);
         return rs_tabs.back().dev;
     }
-    void preprocess_frames(const uint8_t* rgb, int n, int Hh, int Ww, int on_device, float* out_dev) override {
+    void preprocess_frames(const uint8_t* rgb, int n, int Hh, int Ww, int on_device, float* out_dev, bool wait) override {
         REQUIRE(rgb && out_dev, "null frame / output pointer");
         REQUIRE(n >= 1 && Hh >= 1 && Ww >= 1, "bad frame geometry");
         REQUIRE((long long)Hh <= 100ll * Ww, "frames taller than 100 x their width are not supported (Pillow >= 12 resizes them vertical-first)");
@@ -607,7 +626,7 @@ public:
             build_normalize_lut(lut, 0.5f, 0.5f);      // image_mean = image_std = 0.5 (siglip_encoder.py:35)
             d_lut = dalloc<float>(256);
             HIP_CHECK(hipMemcpy(d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
-            for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreate(&pp_ev[i]));
+            for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreate(&h2d_ev[i]));
         }
         const ResampleDev& tabs = resample_tabs(Hh, Ww);
         REQUIRE(tabs.ks_v <= 40, "frame too large for the GPU preprocess kernel (more than 40 source rows per output row)");
@@ -620,29 +639,43 @@ public:
             HIP_CHECK(hipMalloc((void**)&d_rgb, bytes + 256));
             d_rgb_cap = bytes + 256;
         }
-        HIP_CHECK(hipEventRecord(pp_ev[0], st));
+        if (pp_pending == pp_pairs.size()) {
+            if (pp_pairs.size() >= 256) pp_collect();      // bounded pool: fold the finished pairs into the totals and reuse them
+            else {
+                EvPair pr; pr.frames = 0;
+                HIP_CHECK(hipEventCreate(&pr.a)); HIP_CHECK(hipEventCreate(&pr.b));
+                pp_pairs.push_back(pr);
+            }
+        }
+        EvPair& pr = pp_pairs[pp_pending++];
+        pr.frames = n;
+        HIP_CHECK(hipEventRecord(pr.a, st));
         if (on_device) {
             HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, bytes, hipMemcpyDeviceToDevice, st));
         } else {
-            if (h_rgb_cap < bytes) {
+            const int b = h_cur; h_cur ^= 1;
+            if (h_rgb_cap[b] < bytes) {
                 HIP_CHECK(hipStreamSynchronize(st));
-                if (h_rgb) HIP_CHECK(hipHostFree(h_rgb));
-                h_rgb = nullptr; h_rgb_cap = 0;
-                HIP_CHECK(hipHostMalloc((void**)&h_rgb, bytes));
-                h_rgb_cap = bytes;
+                if (h_rgb[b]) HIP_CHECK(hipHostFree(h_rgb[b]));
+                h_rgb[b] = nullptr; h_rgb_cap[b] = 0;
+                HIP_CHECK(hipHostMalloc((void**)&h_rgb[b], bytes));
+                h_rgb_cap[b] = bytes;
             }
-            std::memcpy(h_rgb, rgb, bytes);            // pinned staging: the H2D copy below is a single DMA
-            HIP_CHECK(hipMemcpyAsync(d_rgb, h_rgb, bytes, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipEventSynchronize(h2d_ev[b]));   // the DMA that last read this staging buffer (two calls ago) has finished
+            std::memcpy(h_rgb[b], rgb, bytes);           // pinned staging: the H2D copy below is a single DMA
+            HIP_CHECK(hipMemcpyAsync(d_rgb, h_rgb[b], bytes, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipEventRecord(h2d_ev[b], st));
         }
         launch_preprocess(st, d_rgb, out_dev, n, Hh, Ww, Sx, tabs, d_lut);
         LAUNCH_CHECK("preprocess");
-        HIP_CHECK(hipEventRecord(pp_ev[1], st));
-        HIP_CHECK(hipEventSynchronize(pp_ev[1]));     // out_dev is the caller's tensor: complete before any other stream touches it
-        float t = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&t, pp_ev[0], pp_ev[1]));
-        pp_ms += t; pp_frames += n;
+        HIP_CHECK(hipEventRecord(pr.b, st));
+        // wait: out_dev (the caller's tensor) is complete on return.  Otherwise the work is only enqueued on the engine's stream (the
+        // frame bytes have been consumed): svln_encode_frames on the same engine is ordered behind it, any other stream must wait on
+        // svln_engine_stream() itself.
+        if (wait) HIP_CHECK(hipEventSynchronize(pr.b));
     }
     void preprocess_time(double* ms, int64_t* frames, int reset) override {
+        pp_collect();
         *ms = pp_ms; *frames = pp_frames;
         if (reset) { pp_ms = 0; pp_frames = 0; }
     }
@@ -1434,8 +1467,12 @@ int svln_kv_reset(svln_engine* h, int env) { API_BEGIN_H h->impl->kv_reset(env);
 int svln_env_state(svln_engine* h, int env, int32_t* n_embeds, int32_t* kv_len) { API_BEGIN_H h->impl->env_state(env, n_embeds, kv_len); API_END }
 int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on_device) { API_BEGIN_H h->impl->encode_frames(pixels, n_frames, on_device); API_END }
 int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev) {
-    API_BEGIN_H h->impl->preprocess_frames(rgb, n_frames, height, width, on_device, out_dev); API_END
+    API_BEGIN_H h->impl->preprocess_frames(rgb, n_frames, height, width, on_device, out_dev, true); API_END
 }
+int svln_preprocess_frames_enqueue(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev) {
+    API_BEGIN_H h->impl->preprocess_frames(rgb, n_frames, height, width, on_device, out_dev, false); API_END
+}
+int svln_engine_stream(svln_engine* h, void** stream) { API_BEGIN_H REQUIRE(stream, "null output pointer"); *stream = h->impl->stream_handle(); API_END }
 int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset) { API_BEGIN_H h->impl->preprocess_time(gpu_ms, frames, reset); API_END }
 int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory) { API_BEGIN_H h->impl->append_turn(env, ids, n_ids, 0, n_memory); API_END }
 int svln_append_turn_at(svln_engine* h, int env, const int64_t* ids, int n_ids, int frame_base, int n_memory) {

@@ -27,6 +27,8 @@ SVLN_DEV int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+constexpr int MAX_H = 12;      // horizontal taps whose weights are fetched as one batch of independent loads (longer windows loop on)
+
 template <int MAX_V>
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, const int* __restrict__ hmin,
                                                          const int* __restrict__ hcnt, const int* __restrict__ hk, int ks_h,
@@ -53,10 +55,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
         const uint8_t* px = s_rows + shift + hmin[xx] * 3 + c;
         const int* k = hk + xx * ks_h;
         const int n = hcnt[xx];
+        int kk[MAX_H];                  // the window's weights in one round trip (a load per tap inside the loop serialises on L2 latency)
+#pragma unroll
+        for (int t = 0; t < MAX_H; ++t) kk[t] = t < n ? k[t] : 0;
         int acc[MAX_V];
 #pragma unroll
         for (int r = 0; r < MAX_V; ++r) acc[r] = 1 << (PRECISION_BITS - 1);
-        for (int t = 0; t < n; ++t) {
+#pragma unroll
+        for (int t = 0; t < MAX_H; ++t) {
+            if (t < n) {
+#pragma unroll
+                for (int r = 0; r < MAX_V; ++r)
+                    if (r < cnt) acc[r] += (int)px[r * rowb + 3 * t] * kk[t];
+            }
+        }
+        for (int t = MAX_H; t < n; ++t) {
             const int kt = k[t];
 #pragma unroll
             for (int r = 0; r < MAX_V; ++r)
@@ -68,10 +81,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     }
     __syncthreads();
     // ---- vertical pass (ImagingResampleVertical_8bpc) + rescale / normalise table, channel-planar
-    const int* kv = vk + yy * ks_v;
+    int kvr[MAX_V];                     // this output row's vertical weights, fetched once
+#pragma unroll
+    for (int r = 0; r < MAX_V; ++r) kvr[r] = r < cnt ? vk[yy * ks_v + r] : 0;
     for (int j = tid; j < S3; j += 256) {
         int acc = 1 << (PRECISION_BITS - 1);
-        for (int r = 0; r < cnt; ++r) acc += (int)s_hor[r * S3 + j] * kv[r];
+#pragma unroll
+        for (int r = 0; r < MAX_V; ++r)
+            if (r < cnt) acc += (int)s_hor[r * S3 + j] * kvr[r];
         const int xx = j / 3, c = j - 3 * xx;
         s_out[c * S + xx] = lut[clip8(acc)];
     }

@@ -44,6 +44,7 @@ class SigLipImageProcessor:
         self._engine = engine                 # (lib, handle) of the owning model
         self.device_index = device_index
         self.backend = "hip" if engine is not None else "pil"
+        self._ext_stream = None               # the engine's HIP stream as a torch stream (lazily wrapped)
 
     # -- host path (Pillow) ----------------------------------------------------------------------------
     def _pil(self, rgb) -> torch.Tensor:
@@ -66,14 +67,28 @@ class SigLipImageProcessor:
 
     def _hip(self, frames) -> torch.Tensor:
         """frames: list of uint8 [H,W,3] arrays of one geometry -> CUDA fp32 [n,3,S,S]"""
+        if self._engine is None:
+            raise RuntimeError("the model that owns this image processor was closed")
         lib, h = self._engine
         n, (H, W, _) = len(frames), frames[0].shape
         buf = frames[0] if n == 1 else np.ascontiguousarray(np.stack(frames))
         dev = torch.device("cuda", self.device_index)
         out = torch.empty((n, 3, self.size[0], self.size[1]), dtype=torch.float32, device=dev)
-        torch.cuda.current_stream(dev).synchronize()              # the engine writes `out` on its own stream
-        _check(lib.svln_preprocess_frames(h, buf.ctypes.data_as(C.c_void_p), n, H, W, 0, C.c_void_p(out.data_ptr())))
+        # the engine writes `out` on its own stream: order the two streams on the device instead of stalling the host twice per frame
+        # (the call returns once the frame bytes are staged; svln_encode_frames on the same engine is ordered behind the kernel)
+        ext, cur = self._engine_stream(dev), torch.cuda.current_stream(dev)
+        ext.wait_stream(cur)
+        _check(lib.svln_preprocess_frames_enqueue(h, buf.ctypes.data_as(C.c_void_p), n, H, W, 0, C.c_void_p(out.data_ptr())))
+        cur.wait_stream(ext)      # torch work on `out` (and any later reuse of its memory, which stays on this stream) follows the kernel
         return out
+
+    def _engine_stream(self, dev):
+        if self._ext_stream is None:
+            lib, h = self._engine
+            sp = C.c_void_p()
+            _check(lib.svln_engine_stream(h, C.byref(sp)))
+            self._ext_stream = torch.cuda.ExternalStream(sp.value, device=dev)
+        return self._ext_stream
 
     def preprocess_array(self, rgb) -> torch.Tensor:
         if self.backend == "pil":
@@ -265,6 +280,15 @@ class StreamVLNForCausalLM:
     def get_vision_tower(self):
         return self._tower
 
+    def _order_engine_after(self, pix):
+        """The engine's stream is about to read `pix`: order it behind the torch work that produced the tensor (on the device, no host
+        stall)."""
+        self._tower.image_processor._engine_stream(pix.device).wait_stream(torch.cuda.current_stream(pix.device))
+
+    def _order_torch_after(self, pix):
+        """... and the caller's stream behind that read, so that freeing `pix` cannot hand its memory to later torch work too early."""
+        torch.cuda.current_stream(pix.device).wait_stream(self._tower.image_processor._engine_stream(pix.device))
+
     @property
     def device(self):
         return torch.device("cuda", self.device_index)
@@ -368,8 +392,10 @@ class StreamVLNForCausalLM:
         ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
         on_dev = int(pix.is_cuda)
         if on_dev:
-            torch.cuda.synchronize(pix.device)
+            self._order_engine_after(pix)
         _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+        if on_dev:
+            self._order_torch_after(pix)
         self._begin_turn(env_id, past)
         ids_np = np.ascontiguousarray(ids.numpy())
         _check(self._lib.svln_append_turn(self._h, self._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
@@ -413,8 +439,10 @@ class StreamVLNForCausalLM:
             pix = torch.cat([p[2] for p in parsed[i:j]], 0).contiguous()
             on_dev = int(pix.is_cuda)
             if on_dev:
-                torch.cuda.synchronize(pix.device)
+                self._order_engine_after(pix)
             _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), frames, on_dev))
+            if on_dev:
+                self._order_torch_after(pix)
             base = 0
             for (_, ids, _, V, n_memory, env_id, past, _, _) in parsed[i:j]:
                 self._begin_turn(env_id, past)
@@ -441,8 +469,10 @@ class StreamVLNForCausalLM:
         ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
         on_dev = int(pix.is_cuda)
         if on_dev:
-            torch.cuda.synchronize(pix.device)
+            self._order_engine_after(pix)
         _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+        if on_dev:
+            self._order_torch_after(pix)
         self._begin_turn(env_id, past)
         ids_np = np.ascontiguousarray(ids.numpy())
         _check(self._lib.svln_append_turn(self._h, self._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
@@ -533,6 +563,13 @@ class StreamVLNForCausalLM:
 
     def close(self):
         if getattr(self, "_h", None):
+            proc = self._tower.image_processor
+            if proc._ext_stream is not None:       # nothing on the torch side may still be ordered against the engine's stream
+                proc._ext_stream.synchronize()
+                torch.cuda.current_stream(proc._ext_stream.device).synchronize()
+                proc._ext_stream = None
+            proc._engine = None
+            proc.backend = "closed"
             self._lib.svln_destroy(self._h)
             self._h = None
 

@@ -136,3 +136,39 @@ def test_hip_preprocess_batch_pil_input_and_errors(model):
     proc.backend = "pil"                                                          # explicit host path = Pillow itself
     assert np.array_equal(proc.preprocess_array(frames[0]).numpy(), O.siglip_preprocess(frames[0]))
     proc.backend = "hip"
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_enqueue_ordering_and_blocking_entry(model):
+    """The processor uses the enqueue-only entry (no host wait; ordered against torch's stream on the device): 300 back-to-back calls
+    with distinct frames, results read only afterwards, must each be their own frame's output (double-buffered pinned staging, the
+    timing-event pool wrapping around at 256); the blocking C entry point gives the same bytes."""
+    import ctypes as C
+    from streamvln_amd import _lib
+    proc = model.get_vision_tower().image_processor
+    model.preprocess_time(reset=True)
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, (48, 64, 3), dtype=np.uint8) for _ in range(300)]
+    outs = [proc.preprocess_array(f) for f in frames]                              # nothing synchronises in here
+    sums = torch.stack([o.sum() for o in outs]).cpu().numpy()                      # torch work on the outputs: ordered behind the kernels
+    for i in (0, 1, 2, 127, 255, 256, 257, 299):
+        exp = O.siglip_preprocess(frames[i])
+        assert np.array_equal(outs[i].cpu().numpy(), exp), i
+        assert abs(float(sums[i]) - float(exp.astype(np.float64).sum())) < 1e-2 * max(1.0, abs(float(exp.sum())))
+    ms, n = model.preprocess_time(reset=True)
+    assert n == 300 and ms > 0
+    out = torch.empty((1, 3, 384, 384), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(model._lib.svln_preprocess_frames(model._h, frames[7].ctypes.data_as(C.c_void_p), 1, 48, 64, 0, C.c_void_p(out.data_ptr())))
+    assert np.array_equal(out[0].cpu().numpy(), O.siglip_preprocess(frames[7]))    # complete on return: no sync before the read-back needed
+
+
+@pytest.mark.gpu
+def test_closed_model_processor_raises():
+    from streamvln_amd.model import StreamVLNForCausalLM
+    m = StreamVLNForCausalLM(TINY, dtype=torch.float32, max_envs=1, max_frames=1, max_positions=256)
+    proc = m.get_vision_tower().image_processor
+    proc.preprocess_array(np.zeros((48, 64, 3), dtype=np.uint8))
+    m.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        proc.preprocess_array(np.zeros((48, 64, 3), dtype=np.uint8))
