@@ -630,7 +630,7 @@ public:
         }
         const ResampleDev& tabs = resample_tabs(Hh, Ww);
         REQUIRE(tabs.ks_v <= 40, "frame too large for the GPU preprocess kernel (more than 40 source rows per output row)");
-        REQUIRE(preprocess_lds_bytes(Ww, Sx, tabs.ks_v) <= (size_t)160 * 1024,
+        REQUIRE(preprocess_lds_bytes(Ww, Sx, tabs.ks_v, tabs.ks_h) <= (size_t)160 * 1024,
                 "frame too large for the GPU preprocess kernel (its source rows of one output row must fit the 160 KiB LDS)");
         if (d_rgb_cap < bytes + 64) {
             HIP_CHECK(hipStreamSynchronize(st));

@@ -192,7 +192,7 @@ struct ResampleAxis { int ksize = 0; std::vector<int> xmin, cnt, k; };
 struct ResampleDev { const int *hmin, *hcnt, *hk, *vmin, *vcnt, *vk; int ks_h, ks_v; };   // device copies (h = along the width, v = along the height)
 void build_resample_table(int in_size, int out_size, ResampleAxis& ax);
 void build_normalize_lut(float* lut256, float mean, float std);
-size_t preprocess_lds_bytes(int W, int S, int ks_v);
+size_t preprocess_lds_bytes(int W, int S, int ks_v, int ks_h);
 // rgb uint8 [n][H][W][3] (device, readable up to 16 bytes past its end) -> out fp32 [n][3][S][S]
 void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_frames, int H, int W, int S, const ResampleDev& t, const float* lut);
 void preprocess_init_attrs();

@@ -27,8 +27,6 @@ SVLN_DEV int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-constexpr int MAX_H = 12;      // horizontal taps whose weights are fetched as one batch of independent loads (longer windows loop on)
-
 template <int MAX_V>
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ out, const int* __restrict__ hmin,
                                                          const int* __restrict__ hcnt, const int* __restrict__ hk, int ks_h,
@@ -38,38 +36,37 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     uint8_t* s_rows = (uint8_t*)smem;                         // staged source rows (+ up to 15 leading bytes of alignment slack)
     uint8_t* s_hor = s_rows + rows_cap_bytes;                 // [ks_v][3 S] horizontally resampled bytes
     float* s_out = (float*)(s_hor + ((ks_v * 3 * S + 15) & ~15));   // [3][S]
+    int* s_hmin = (int*)(s_out + 3 * S);                      // the horizontal tables, staged with the rows in the same round trip:
+    int* s_hcnt = s_hmin + S;                                 //   a lookup per output byte from global memory would put two dependent
+    int* s_hk = s_hcnt + S;                                   //   L2 round trips into every iteration of the horizontal pass
+    float* s_lut = (float*)(s_hk + S * ks_h);
     const int yy = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const int S3 = 3 * S, rowb = 3 * W;
     const int y0 = vmin[yy], cnt = vcnt[yy];
-    // ---- stage rows y0 .. y0+cnt-1 (contiguous in memory)
+    // ---- stage rows y0 .. y0+cnt-1 (contiguous in memory) and the tables
     const size_t off = ((size_t)f * H + y0) * rowb;
     const size_t a0 = off & ~(size_t)15;
     const int shift = (int)(off - a0);
     const int nchunks = (shift + cnt * rowb + 15) >> 4;
     for (int i = tid; i < nchunks; i += 256) smem[i] = *(const uint4*)(rgb + a0 + (size_t)i * 16);
+    for (int i = tid; i < S; i += 256) { s_hmin[i] = hmin[i]; s_hcnt[i] = hcnt[i]; }
+    for (int i = tid; i < S * ks_h; i += 256) s_hk[i] = hk[i];
+    s_lut[tid] = lut[tid];
+    int kvr[MAX_V];                     // this output row's vertical weights (workgroup-uniform)
+#pragma unroll
+    for (int r = 0; r < MAX_V; ++r) kvr[r] = r < cnt ? vk[yy * ks_v + r] : 0;
     __syncthreads();
     // ---- horizontal pass (ImagingResampleHorizontal_8bpc): a thread owns output bytes j = tid, tid + 256, ... of EVERY staged row, so
     // the byte's column, channel, window and weights are set up once and reused for the <= ks_v rows
     for (int j = tid; j < S3; j += 256) {
         const int xx = j / 3, c = j - 3 * xx;
-        const uint8_t* px = s_rows + shift + hmin[xx] * 3 + c;
-        const int* k = hk + xx * ks_h;
-        const int n = hcnt[xx];
-        int kk[MAX_H];                  // the window's weights in one round trip (a load per tap inside the loop serialises on L2 latency)
-#pragma unroll
-        for (int t = 0; t < MAX_H; ++t) kk[t] = t < n ? k[t] : 0;
+        const uint8_t* px = s_rows + shift + s_hmin[xx] * 3 + c;
+        const int* k = s_hk + xx * ks_h;
+        const int n = s_hcnt[xx];
         int acc[MAX_V];
 #pragma unroll
         for (int r = 0; r < MAX_V; ++r) acc[r] = 1 << (PRECISION_BITS - 1);
-#pragma unroll
-        for (int t = 0; t < MAX_H; ++t) {
-            if (t < n) {
-#pragma unroll
-                for (int r = 0; r < MAX_V; ++r)
-                    if (r < cnt) acc[r] += (int)px[r * rowb + 3 * t] * kk[t];
-            }
-        }
-        for (int t = MAX_H; t < n; ++t) {
+        for (int t = 0; t < n; ++t) {
             const int kt = k[t];
 #pragma unroll
             for (int r = 0; r < MAX_V; ++r)
@@ -81,16 +78,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     }
     __syncthreads();
     // ---- vertical pass (ImagingResampleVertical_8bpc) + rescale / normalise table, channel-planar
-    int kvr[MAX_V];                     // this output row's vertical weights, fetched once
-#pragma unroll
-    for (int r = 0; r < MAX_V; ++r) kvr[r] = r < cnt ? vk[yy * ks_v + r] : 0;
     for (int j = tid; j < S3; j += 256) {
         int acc = 1 << (PRECISION_BITS - 1);
 #pragma unroll
         for (int r = 0; r < MAX_V; ++r)
             if (r < cnt) acc += (int)s_hor[r * S3 + j] * kvr[r];
         const int xx = j / 3, c = j - 3 * xx;
-        s_out[c * S + xx] = lut[clip8(acc)];
+        s_out[c * S + xx] = s_lut[clip8(acc)];
     }
     __syncthreads();
     for (int i = tid; i < S3; i += 256) {
@@ -149,14 +143,15 @@ void build_normalize_lut(float* lut256, float mean, float std) {
     }
 }
 
-size_t preprocess_lds_bytes(int W, int S, int ks_v) {
+size_t preprocess_lds_bytes(int W, int S, int ks_v, int ks_h) {
     const size_t rows = (((size_t)ks_v * 3 * W + 15 + 15) & ~(size_t)15) + 16;
-    return rows + (((size_t)ks_v * 3 * S + 15) & ~(size_t)15) + (size_t)3 * S * sizeof(float);
+    return rows + (((size_t)ks_v * 3 * S + 15) & ~(size_t)15) + (size_t)3 * S * sizeof(float)       // staged rows, horizontal bytes, output row
+           + (size_t)S * (2 + ks_h) * sizeof(int) + 256 * sizeof(float);                            // horizontal tables, normalise table
 }
 
 void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_frames, int H, int W, int S, const ResampleDev& t, const float* lut) {
     const int rows_cap = (int)((((size_t)t.ks_v * 3 * W + 15 + 15) & ~(size_t)15) + 16);
-    const size_t lds = preprocess_lds_bytes(W, S, t.ks_v);
+    const size_t lds = preprocess_lds_bytes(W, S, t.ks_v, t.ks_h);
     // the vertical window (ks_v source rows per output row) is a compile-time bound of the per-thread accumulators
     if (t.ks_v <= 8)
         hipLaunchKernelGGL(preprocess_kernel<8>, dim3(S, n_frames), dim3(256), lds, s, rgb, out, t.hmin, t.hcnt, t.hk, t.ks_h, t.vmin, t.vcnt, t.vk, t.ks_v,
