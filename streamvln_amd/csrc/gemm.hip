@@ -50,8 +50,8 @@ using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
-using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: products with few 128-wide column
-                                                             // tiles and a short K (ViT out_proj, N = K = 1152) get >= 200 workgroups WITHOUT a K split (no fp32 slabs)
+using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
+                                                             // products with few 128-wide column tiles and a short K (force_cfg 64 only, see launch_epi)
 using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockstep decode of several envs): 2 waves, 20 KB stages, glds kernel only
 using CfgBig4 = TileCfg<256, 256, 2, 2, 128, false, 2>;      // 4 waves, wave tile 128x128 (4x4 accumulators in AGPRs): half the LDS fragment reads per MFMA       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
 
@@ -707,10 +707,11 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         if (!ok) a.force_split = 1;
         while (a.force_split > 1 && (size_t)a.force_split * a.M * a.N > a.ws_elems) --a.force_split;
     }
-    // Tile choice (measured on MI355X, tools/kbench.py):
+    // Tile choice (measured on MI355X: tools/kbench.py for single launches, the kernel trace of bench.py for the choice inside a turn):
     //   M <= 256            -> 256x128 tiles + split-K: one row tile, every weight byte staged once
-    //   M  > 256, >= 96 tiles of 128x128 -> 128x128 tiles, no split (2 workgroups per CU overlap each other's phases)
-    //   otherwise (few tiles, long K: ViT fc2, o/down at T = 376) -> 256x128 tiles + split-K
+    //   M  > 256, >= 256 tiles of 128x128 (a full round at two workgroups per CU) -> 128x128 tiles, no split
+    //   otherwise (less than a round of 128x128 tiles: every one-frame ViT product, o/down at T = 376) -> 256x128 tiles + split-K: inside the
+    //   turn the K-split launch + reduce beats the half-empty unsplit launch (one-frame ViT fc1: 16.8 + 10.0 us against 31.4; qkv equal)
     //   large M AND N (>= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
     //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel
     // M <= 32 (several envs decoded in lockstep): 32x128 tiles, 2 waves, three 20 KB stages in flight per workgroup and two
@@ -741,20 +742,19 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
 
     const int fc = a.force_cfg & 0xFFF;
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    // several row tiles, few 128-wide column tiles and a short K (one-frame ViT out_proj: 729 x 1152 x 1152): 64x64 tiles fill the chip
-    // without a K split -- no fp32 slabs, no reduce pass; the caller runs the following norm itself (launch_gemm returns false).
-    // Measured: 12.7 us against 14.1 + 6.2 (split + reduce); at K = 4304 (fc2) the split path wins, 20 + 6 against 36.
+    // 64x64 tiles (no K split, no fp32 slabs) for several row tiles, few 128-wide column tiles and a short K -- the one-frame ViT out_proj,
+    // 729 x 1152 x 1152 -- are only reachable through force_cfg: on isolated launches they win (12.7 us against 14.1 + 6.2 for split +
+    // reduce), but inside the turn the caller then has to run the following LayerNorm itself and the pair measured 19.4 + 5.0 us against
+    // 10.9 + 10.2 for the K-split product whose reduce emits the norm (one-frame ViT 3.69 -> 3.60 ms).
     // (Also measured and NOT kept: a 4-deep ring for one-round 128x128 launches, 19.9 vs 19.4 us on ViT qkv; issuing the LDS-DMA
     //  pieces of the next stage one by one between the MFMAs instead of as a burst ahead of them: 5-25 % slower on every config.)
-    const int tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
-    const bool want64 = a.zeros && a.M > 256 && a.N <= 2048 && a.K <= 2048 && tiles128 < 96 && tiles64 <= 512;
-    if ((want64 && a.force_split == 0 && fc == 0) || (fc == 64 && a.zeros)) {
+    if (fc == 64 && a.zeros) {
         a.nsplit = 1;
-        a.launch_tiles = tiles64;
+        a.launch_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
         launch_cfg<T, EPI, Cfg64, false>(s, a, 1);
         return false;
     }
-    const bool want128 = a.M > 256 && tiles128 >= 96;
+    const bool want128 = a.M > 256 && tiles128 >= 256;
     if ((want128 && a.force_split == 0) || fc == 128) {
         a.nsplit = 1;
         a.launch_tiles = tiles128;

@@ -39,7 +39,7 @@ def chk(rc):
     (130, 1152, 4304, _lib.EPI_NONE, True, True),        # ViT fc2: K not a multiple of the stage
     (64, 256, 592, _lib.EPI_GELU_ERF, True, False),      # patch-embed K
     (1, 128, 64, _lib.EPI_NONE, False, False),           # degenerate
-    (729, 1152, 1152, _lib.EPI_NONE, True, True),        # ViT out_proj at one frame: the heuristic takes 64x64 tiles, no K split
+    (729, 1152, 1152, _lib.EPI_NONE, True, True),        # ViT out_proj at one frame
 ])
 def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     if cfgsplit[0] == 32 and M > 32:
@@ -72,9 +72,10 @@ def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     (37, 3584, 3584, 4, "rms", True),       # o_proj at true width, ragged M
     (212, 3584, 18944 // 8, 3, "rms", True),    # down_proj-like
     (1, 512, 512, 2, "rms", True),
-    (700, 2048, 1024, 0, "rms", False),     # many 128x128 tiles -> unsplit: the caller must run the norm itself
-    (729, 1152, 1152, 0, "ln", False),      # SigLIP out_proj, one frame: 64x64 tiles without a K split -> the caller runs layer_norm2
-    (729, 1152, 1152, 9, "ln", True),       # ... and with a forced K split the reduce emits it
+    (1400, 4096, 512, 0, "rms", False),     # a full round of 128x128 tiles -> unsplit: the caller must run the norm itself
+    (700, 2048, 1024, 0, "rms", True),      # less than a round of them -> K-split product, fused
+    (729, 1152, 1152, 0, "ln", True),       # SigLIP out_proj, one frame: K-split product, the reduce emits layer_norm2
+    (729, 1152, 1152, 9, "ln", True),       # ... also with a forced split count
     (729, 1152, 4304, 8, "ln", True),       # SigLIP fc2 -> next layer_norm1
     (50, 144, 288, 2, "ln", True),
 ])
