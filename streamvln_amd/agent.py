@@ -51,11 +51,15 @@ class StreamingAgent:
                  num_history: Optional[int] = 8, env_id: int = 0, device: str = "cpu",
                  image_dtype: torch.dtype = torch.float32, max_new_tokens: int = 10000,
                  eos_token_ids: Sequence[int] = (), decode_actions: Optional[Callable] = None,
-                 preprocess: Optional[Callable] = None):
+                 preprocess: Optional[Callable] = None, ids_device: Optional[str] = "cpu"):
         self.model = model
         self.prompt_encoder = prompt_encoder
         self.num_frames, self.num_future_steps, self.num_history = num_frames, num_future_steps, num_history
         self.env_id, self.device, self.image_dtype = env_id, device, image_dtype
+        # the reference callers put `inputs` on the model's device (streamvln_eval.py:326); the engine takes token ids from the host, so
+        # this agent leaves them there (no H2D + D2H of a few dozen ids per turn; `sequences` come back on the same device).  None = as
+        # the reference: `device`.  The model accepts both.
+        self.ids_device = device if ids_device is None else ids_device
         self.max_new_tokens, self.eos_token_ids = max_new_tokens, tuple(eos_token_ids)
         self.decode_actions = decode_actions or (lambda ids: [1] * num_future_steps)
         if preprocess is None:
@@ -98,7 +102,7 @@ class StreamingAgent:
             "images": torch.stack(images).unsqueeze(0).to(self.device).to(self.image_dtype),
             # depths / poses / intrinsics are built by the reference callers and ignored by the model
             "depths": torch.zeros(1, V, 1, 1), "poses": torch.zeros(1, V, 4, 4), "intrinsics": torch.zeros(1, V, 4, 4),
-            "inputs": ids.to(self.device), "env_id": env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
+            "inputs": ids.to(self.ids_device), "env_id": env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
             "do_sample": False, "num_beams": 1, "max_new_tokens": self.max_new_tokens, "use_cache": True,
             "return_dict_in_generate": True, "past_key_values": self.past_key_values, "eos_token_ids": self.eos_token_ids,
         }

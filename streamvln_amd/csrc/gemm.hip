@@ -770,6 +770,8 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     const int tiles256 = tiles_m * tiles_n;
     const int stages = (a.K / EPC + Cfg256::CH - 1) / Cfg256::CH;
     const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
+    // (re-measured inside the turn: capping the split count at 4 / 6 instead of filling one round of 256 workgroups costs 0.75 / 0.25 ms of
+    //  steady prefill per turn -- the shorter K chains are worth more than the smaller fp32 slabs)
     auto pick = [&](int tiles) {
         int S = 256 / tiles;
         if (S < 1) S = 1;
