@@ -412,6 +412,7 @@ def main():
                        "decode_graph": not a.no_graph, "parallelism": f"episode-parallel x{world}"},
             "per_gpu": round(value / world, 2),
             "p50_ms_per_turn": round(float(np.median(lat)) * 1e3, 3),
+            "turn_ms": [round(x * 1e3, 2) for x in lat],
             # preprocess = wall time inside the image processor (host memcpy to pinned staging + H2D + kernel + sync), 4 frames per turn;
             # preprocess_gpu = the device part of it (HIP events); vision / prefill / decode = HIP events on the engine's stream
             "phase_ms_per_turn": {"preprocess": round(pre_wall_s / a.steps * 1e3, 3), "preprocess_gpu": round(pre_gpu_ms / a.steps, 3),
