@@ -357,7 +357,7 @@ public:
             if (h_rgb[i]) (void)hipHostFree(h_rgb[i]);
             if (h2d_ev[i]) (void)hipEventDestroy(h2d_ev[i]);
         }
-        for (auto& pr : pp_pairs) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+        for (auto& pr : pp_ring) { if (pr.a) (void)hipEventDestroy(pr.a); if (pr.b) (void)hipEventDestroy(pr.b); }
         if (src_ev) (void)hipEventDestroy(src_ev);
         for (auto e : probe_ev) (void)hipEventDestroy(e);
         for (auto e : pprobe_ev) (void)hipEventDestroy(e);
@@ -583,19 +583,21 @@ public:
     uint8_t* d_rgb = nullptr; size_t d_rgb_cap = 0; float* d_lut = nullptr;
     // pinned staging, double-buffered: call i + 1 copies its frame in while the DMA of call i may still be reading the other buffer
     uint8_t* h_rgb[2] = {nullptr, nullptr}; size_t h_rgb_cap[2] = {0, 0}; hipEvent_t h2d_ev[2] = {nullptr, nullptr}; int h_cur = 0;
-    // GPU time of the preprocess calls: (begin, end) event pairs, read back lazily so that an enqueue-only call never waits
-    struct EvPair { hipEvent_t a, b; int frames; };
-    std::vector<EvPair> pp_pairs; size_t pp_pending = 0;
+    // GPU time of the preprocess calls: a fixed ring of (begin, end) event pairs created with the first call and read back lazily (when the
+    // ring wraps, or when the totals are asked for), so that an enqueue-only call neither waits nor creates events -- event creation on
+    // the hot path stalls for milliseconds whenever the runtime grows its signal pool
+    static constexpr int PP_RING = 16;
+    struct EvPair { hipEvent_t a = nullptr, b = nullptr; int frames = 0; };
+    EvPair pp_ring[PP_RING]; size_t pp_head = 0, pp_tail = 0;      // pairs [pp_tail, pp_head) are pending
     double pp_ms = 0; int64_t pp_frames = 0;
-    void pp_collect() {
-        for (size_t i = 0; i < pp_pending; ++i) {
-            float t = 0.f;
-            HIP_CHECK(hipEventSynchronize(pp_pairs[i].b));
-            HIP_CHECK(hipEventElapsedTime(&t, pp_pairs[i].a, pp_pairs[i].b));
-            pp_ms += t; pp_frames += pp_pairs[i].frames;
-        }
-        pp_pending = 0;
+    void pp_resolve_oldest() {
+        EvPair& pr = pp_ring[pp_tail++ % PP_RING];
+        float t = 0.f;
+        HIP_CHECK(hipEventSynchronize(pr.b));
+        HIP_CHECK(hipEventElapsedTime(&t, pr.a, pr.b));
+        pp_ms += t; pp_frames += pr.frames;
     }
+    void pp_collect() { while (pp_tail < pp_head) pp_resolve_oldest(); }
     void* stream_handle() override { return (void*)st; }
     const ResampleDev& resample_tabs(int Hh, int Ww) {
         for (auto& t : rs_tabs) if (t.H == Hh && t.W == Ww) return t.dev;
@@ -627,6 +629,7 @@ public:
             d_lut = dalloc<float>(256);
             HIP_CHECK(hipMemcpy(d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
             for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreate(&h2d_ev[i]));
+            for (auto& pr : pp_ring) { HIP_CHECK(hipEventCreate(&pr.a)); HIP_CHECK(hipEventCreate(&pr.b)); }
         }
         const ResampleDev& tabs = resample_tabs(Hh, Ww);
         REQUIRE(tabs.ks_v <= 40, "frame too large for the GPU preprocess kernel (more than 40 source rows per output row)");
@@ -639,15 +642,8 @@ public:
             HIP_CHECK(hipMalloc((void**)&d_rgb, bytes + 256));
             d_rgb_cap = bytes + 256;
         }
-        if (pp_pending == pp_pairs.size()) {
-            if (pp_pairs.size() >= 256) pp_collect();      // bounded pool: fold the finished pairs into the totals and reuse them
-            else {
-                EvPair pr; pr.frames = 0;
-                HIP_CHECK(hipEventCreate(&pr.a)); HIP_CHECK(hipEventCreate(&pr.b));
-                pp_pairs.push_back(pr);
-            }
-        }
-        EvPair& pr = pp_pairs[pp_pending++];
+        if (pp_head - pp_tail == PP_RING) pp_resolve_oldest();      // 16 calls old: finished long ago
+        EvPair& pr = pp_ring[pp_head++ % PP_RING];
         pr.frames = n;
         HIP_CHECK(hipEventRecord(pr.a, st));
         if (on_device) {

@@ -142,7 +142,7 @@ def test_hip_preprocess_batch_pil_input_and_errors(model):
 def test_hip_preprocess_enqueue_ordering_and_blocking_entry(model):
     """The processor uses the enqueue-only entry (no host wait; ordered against torch's stream on the device): 300 back-to-back calls
     with distinct frames, results read only afterwards, must each be their own frame's output (double-buffered pinned staging, the
-    timing-event pool wrapping around at 256); the blocking C entry point gives the same bytes."""
+    timing-event ring wrapping around many times); the blocking C entry point gives the same bytes."""
     import ctypes as C
     from streamvln_amd import _lib
     proc = model.get_vision_tower().image_processor

@@ -33,11 +33,11 @@ wrap(run.agent, "_build_request", "agent._build_request")
 wrap(model, "_parse_call", "model._parse_call")
 wrap(model, "generate", "model.generate")
 d3 = [C.c_double() for _ in range(3)]
-for i in range(30):
+for i in range(40):
     acc.clear()
     lib0.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 1)
     t = time.perf_counter(); run.turn(); model.sync(); w = (time.perf_counter() - t) * 1e3
     lib0.svln_phase_times(h, C.byref(d3[0]), C.byref(d3[1]), C.byref(d3[2]), 0)
-    if w > 40 or i in (7, 23):
+    if w > 24 or i in (7,):
         print(f"turn {i}: wall {w:.2f} ms  gpu phases v/p/d {d3[0].value:.2f} {d3[1].value:.2f} {d3[2].value:.2f}  " +
               "  ".join(f"{k} {v * 1e3:.2f}" for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:7]))
