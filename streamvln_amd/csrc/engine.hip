@@ -582,7 +582,7 @@ public:
     std::vector<ResampleTabs> rs_tabs;
     uint8_t* d_rgb = nullptr; size_t d_rgb_cap = 0; float* d_lut = nullptr;
     // pinned staging, double-buffered: call i + 1 copies its frame in while the DMA of call i may still be reading the other buffer
-    uint8_t* h_rgb[2] = {nullptr, nullptr}; size_t h_rgb_cap[2] = {0, 0}; hipEvent_t h2d_ev[2] = {nullptr, nullptr}; int h_cur = 0;
+    uint8_t* h_rgb[2] = {nullptr, nullptr}; uint8_t* h_rgb_dev[2] = {nullptr, nullptr}; size_t h_rgb_cap[2] = {0, 0}; hipEvent_t h2d_ev[2] = {nullptr, nullptr}; int h_cur = 0;
     // GPU time of the preprocess calls: a fixed ring of (begin, end) event pairs created with the first call and read back lazily (when the
     // ring wraps, or when the totals are asked for), so that an enqueue-only call neither waits nor creates events -- event creation on
     // the hot path stalls for milliseconds whenever the runtime grows its signal pool
@@ -654,12 +654,13 @@ public:
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (h_rgb[b]) HIP_CHECK(hipHostFree(h_rgb[b]));
                 h_rgb[b] = nullptr; h_rgb_cap[b] = 0;
-                HIP_CHECK(hipHostMalloc((void**)&h_rgb[b], bytes));
+                HIP_CHECK(hipHostMalloc((void**)&h_rgb[b], bytes + 16));
+                HIP_CHECK(hipHostGetDevicePointer((void**)&h_rgb_dev[b], h_rgb[b], 0));
                 h_rgb_cap[b] = bytes;
             }
             HIP_CHECK(hipEventSynchronize(h2d_ev[b]));   // the DMA that last read this staging buffer (two calls ago) has finished
-            std::memcpy(h_rgb[b], rgb, bytes);           // pinned staging: the H2D copy below is a single DMA
-            HIP_CHECK(hipMemcpyAsync(d_rgb, h_rgb[b], bytes, hipMemcpyHostToDevice, st));
+            std::memcpy(h_rgb[b], rgb, bytes);           // pinned, device-mapped staging: the upload below is one kernel reading it over PCIe
+            launch_upload(st, h_rgb_dev[b], d_rgb, bytes);
             HIP_CHECK(hipEventRecord(h2d_ev[b], st));
         }
         launch_preprocess(st, d_rgb, out_dev, n, Hh, Ww, Sx, tabs, d_lut);

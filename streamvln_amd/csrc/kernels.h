@@ -195,6 +195,7 @@ void build_normalize_lut(float* lut256, float mean, float std);
 size_t preprocess_lds_bytes(int W, int S, int ks_v, int ks_h);
 // rgb uint8 [n][H][W][3] (device, readable up to 16 bytes past its end) -> out fp32 [n][3][S][S]
 void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_frames, int H, int W, int S, const ResampleDev& t, const float* lut);
+void launch_upload(hipStream_t s, const void* src_dev_visible, void* dst, size_t bytes);    // 16-byte granules; src may be pinned host memory
 void preprocess_init_attrs();
 
 // raise the dynamic-LDS limit of the kernels that may ask for more than 64 KiB (call once, outside capture).  A refused attribute would

@@ -7,7 +7,8 @@
 // the vertical pass over its uint8 result.  Rescale + normalise map each of the 256 byte levels to one fp32 value (host-built table,
 // the fp64-multiply / fp32-cast / fp32-subtract-divide sequence of transformers' rescale / normalize).
 //
-// One launch: a workgroup owns one output row of one frame.  Its <= ks_v source rows are one contiguous byte range of the frame:
+// The frame comes up from pinned host staging through upload_kernel below (no runtime copy), then
+// one launch: a workgroup owns one output row of one frame.  Its <= ks_v source rows are one contiguous byte range of the frame:
 // staged into LDS with 16-byte loads, resampled horizontally into an LDS byte image [ks_v][3 S], then combined vertically; the
 // three channel rows go out as full contiguous fp32 rows (CHW).  Integer work, HBM/L2-bound: 0.92 MB in, 1.77 MB out per frame.
 #include <cmath>
@@ -93,6 +94,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     }
 }
 
+// frame upload as a kernel: 16-byte loads straight from the pinned (device-mapped) staging buffer, 16-byte stores to HBM -- one launch
+// instead of a runtime copy (hipMemcpyAsync from pinned memory stalled its caller for ~7 ms every few dozen calls on this runtime)
+__global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 double bicubic_filter(double x) {                            // Resample.c bicubic_filter, a = -0.5
 #pragma clang fp contract(off)
     const double a = -0.5;
@@ -162,6 +170,12 @@ void launch_preprocess(hipStream_t s, const uint8_t* rgb, float* out, int n_fram
     else
         hipLaunchKernelGGL(preprocess_kernel<40>, dim3(S, n_frames), dim3(256), lds, s, rgb, out, t.hmin, t.hcnt, t.hk, t.ks_h, t.vmin, t.vcnt, t.vk, t.ks_v,
                            lut, H, W, S, rows_cap);
+}
+
+// bytes rounded up to 16: both buffers are allocated with that slack
+void launch_upload(hipStream_t s, const void* src_dev_visible, void* dst, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)src_dev_visible, (uint4*)dst, n16);
 }
 
 void preprocess_init_attrs() {
