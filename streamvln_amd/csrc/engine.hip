@@ -448,7 +448,7 @@ public:
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
         a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
-        a.a_scale = nullptr; a.w_scale = nullptr; a.rope = nullptr; return a;
+        a.a_scale = nullptr; a.w_scale = nullptr; a.rope = nullptr; a.vitpack = nullptr; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
         AttnArgs a; std::memset(&a, 0, sizeof(a));
@@ -463,8 +463,8 @@ public:
         }
         return a;
     }
-    void vit_attention(const void* qkv_buf, int ld, int F, void* out, int o_stride) {
-        launch_vit_kv_pack<T>(st, qkv_buf, ld, vkpool, vvpool, F, S, vheads, vhd);
+    void vit_attention(const void* qkv_buf, int ld, int F, void* out, int o_stride, bool packed = false) {
+        if (!packed) launch_vit_kv_pack<T>(st, qkv_buf, ld, vkpool, vvpool, F, S, vheads, vhd);
         AttnArgs a = vit_attn_args(qkv_buf, ld, F, out, o_stride);
         launch_attention<T>(st, a, vhd, 4);
         if (a.nsplit > 1) launch_attention_combine<T>(st, a, vhd);
@@ -479,8 +479,12 @@ public:
         for (int i = 0; i < c.v_layers; ++i) {      // SigLipEncoderLayer (siglip_encoder.py:269-305)
             const VLayer& L = vl[i];
             if (!vn_ready) launch_layernorm<T>(st, vx, L.ln1_w, L.ln1_b, vn, M, Hv, c.v_eps);
-            launch_gemm<T>(st, gemm_args(vn, Hv, L.qkv_w, Hv, vqkv, 3 * Hv, L.qkv_b, nullptr, 0, 0, M, 3 * Hv, Hv, EPI_NONE));
-            vit_attention(vqkv, 3 * Hv, F, vattn, Hv);
+            // (one frame: the product runs split-K and its slab reduce also packs the K / V^T pages of the attention)
+            GemmArgs aq = gemm_args(vn, Hv, L.qkv_w, Hv, vqkv, 3 * Hv, L.qkv_b, nullptr, 0, 0, M, 3 * Hv, Hv, EPI_NONE);
+            const VitPackArgs vpk{vkpool, vvpool, F, S, vheads, vhd};
+            aq.vitpack = &vpk;
+            const bool packed = launch_gemm<T>(st, aq);
+            vit_attention(vqkv, 3 * Hv, F, vattn, Hv, packed);
             // out_proj / fc2 run split-K at one frame: their slab reduce also emits the following LayerNorm
             GemmArgs ao = gemm_args(vattn, Hv, L.out_w, Hv, vx, Hv, L.out_b, vx, Hv, 0, M, Hv, Hv, EPI_NONE);
             ao.norm_w = L.ln2_w; ao.norm_b = L.ln2_b; ao.norm_out = vn; ao.norm_eps = c.v_eps;

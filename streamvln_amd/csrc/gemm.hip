@@ -659,6 +659,73 @@ __global__ __launch_bounds__(64) void splitk_qkv_rope_kernel(GemmArgs p, RopeKvA
     }
 }
 
+// Split-K reduce of the SigLIP QKV product fused with the K / V^T packing of the ViT attention: C = round(sum_s slab + bias) for the
+// q | k | v columns of one (64-key tile, frame * head), then the k rows go to the K page (zero padded to HDP) and the v rows through an
+// LDS tile to the transposed V page -- splitk_epilogue_kernel followed by vit_kv_pack_kernel (misc.hip) in one pass, same values.
+// grid (key tiles, F * heads, 3 parts), 256 threads.  C keeps all three parts (the attention reads q from it).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_qkv_vitpack_kernel(GemmArgs p, VitPackArgs v) {
+    extern __shared__ __attribute__((aligned(16))) char vp_smem[];
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    T* vt = (T*)vp_smem;                                    // [64 keys][HD + EPC]
+    const int tile = blockIdx.x, kh = blockIdx.y;
+    const int f = kh / v.heads, head = kh % v.heads, HD = v.head_dim, Hv = v.heads * HD;
+    const int hdc = (((HD + EPC - 1) / EPC) + 1) & ~1, HDP = hdc * EPC, VROWS = ((HD + 31) / 32) * 32;
+    const int nkv = v.F * v.heads, pitch = HD + EPC, q4 = HD / 4;
+    const size_t slab = (size_t)p.M * p.N;
+    const T* bias = (const T*)p.bias;
+    T* Cc = (T*)p.C;
+    T* kp = (T*)v.Kpool + ((size_t)tile * nkv + kh) * 64 * HDP;
+    T* vp = (T*)v.Vpool + ((size_t)tile * nkv + kh) * VROWS * 64;
+    // blockIdx.z = part (0 = q, 1 = k, 2 = v): 576 workgroups per frame keep enough slab loads in flight; one thread = 4 consecutive
+    // columns of one key row
+    const int part = blockIdx.z;
+    for (int e = threadIdx.x; e < 64 * q4; e += 256) {
+        const int key = e / q4, c4 = (e - key * q4) * 4;
+        const int srow = tile * 64 + key, col = part * Hv + head * HD + c4;
+        T o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(0.0f);
+        if (srow < v.S) {
+            const size_t row = (size_t)f * v.S + srow;
+            const float* src = p.ws + row * p.N + col;
+            float a[4] = {0, 0, 0, 0};
+            for (int s = 0; s < p.nsplit; ++s) {
+                const float4 t = *(const float4*)(src + s * slab);
+                a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(a[j] + (bias ? to_f32(bias[col + j]) : 0.0f));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cc[row * p.ldc + col + j] = o[j];
+        }
+        if (part == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kp[(size_t)key * HDP + c4 + j] = o[j];
+        } else if (part == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vt[key * pitch + c4 + j] = o[j];
+        }
+    }
+    if (part == 0) return;
+    if (part == 1) {
+        for (int e = threadIdx.x; e < 64 * (HDP - HD); e += 256) {          // zero padding of the K rows
+            const int key = e / (HDP - HD), c = HD + e % (HDP - HD);
+            kp[(size_t)key * HDP + c] = from_f32<T>(0.0f);
+        }
+        return;
+    }
+    __syncthreads();
+    constexpr int KC = 64 / EPC;                            // key chunks per Vt row
+    for (int e = threadIdx.x; e < VROWS * KC; e += 256) {
+        const int d = e / KC, kc = e % KC;
+        T out[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) out[j] = d < HD ? vt[(kc * EPC + j) * pitch + d] : from_f32<T>(0.0f);
+        *(uint4*)(vp + (size_t)d * 64 + kc * EPC) = *(const uint4*)out;
+    }
+}
+
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
@@ -683,6 +750,13 @@ template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_
     launch_cfg<T, EPI, C, true>(s, a, S);
     if (EPI == EPI_NONE && a.norm_out && a.norm_w && a.tile_base == 0 && a.N <= 4096 && a.N % 4 == 0) {
         hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(((a.N / 4 + 63) / 64) * 64), 0, s, a);
+        return true;
+    }
+    if (EPI == EPI_NONE && a.vitpack && a.tile_base == 0 && !a.res && a.N == 3 * a.vitpack->heads * a.vitpack->head_dim &&
+        a.M == a.vitpack->F * a.vitpack->S && a.vitpack->head_dim % 4 == 0) {
+        const VitPackArgs& v = *a.vitpack;
+        const size_t lds = (size_t)64 * (v.head_dim + Elt<T>::PER_CHUNK) * sizeof(T);
+        hipLaunchKernelGGL((splitk_qkv_vitpack_kernel<T>), dim3((v.S + 63) / 64, v.F * v.heads, 3), dim3(256), lds, s, a, v);
         return true;
     }
     if (EPI == EPI_NONE && a.rope && a.tile_base == 0 && !a.res && a.N == (a.rope->nq + 2 * a.rope->nkv) * 128 && a.M == a.rope->T) {

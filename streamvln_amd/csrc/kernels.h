@@ -12,6 +12,8 @@ namespace svln {
 enum Epi : int { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4 };
 
 struct RopeKvArgs;
+// K / V^T pools of the ViT attention (layout of launch_vit_kv_pack): the fused tail of the SigLIP QKV product
+struct VitPackArgs { void* Kpool; void* Vpool; int F, S, heads, head_dim; };
 // C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]) + res[row % res_mod or row][N]      (all T, fp32 accumulate)
 // K, lda, ldw multiples of one 16-byte chunk; EPI_SWIGLU: W rows are 32-row blocks
 // [gate 32 | up 32] and C is [M, N/2] = silu(gate) * up.
@@ -34,6 +36,10 @@ struct GemmArgs {
     // split-K path the slab reduce also applies RoPE and appends k / v^T to the paged cache (rope->qkv must be C) and launch_gemm
     // returns true; otherwise C holds the plain product + bias and the caller runs launch_rope_kv itself
     const RopeKvArgs* rope;
+    // optional fused tail of the SigLIP QKV product (siglip_encoder.py:197-232): when the product takes the split-K path the slab reduce
+    // (sum + bias, rounded to T) also writes the K pages and the transposed V pages of the ViT attention -- splitk_epilogue followed by
+    // vit_kv_pack in one pass -- and launch_gemm returns true; otherwise the caller runs launch_vit_kv_pack itself
+    const VitPackArgs* vitpack;
     const void* norm_b;           // non-null: LayerNorm (mean/variance, weight norm_w, bias norm_b) instead of RMSNorm -- the ViT's ln1 / ln2
     // opt-in fp8 (OCP e4m3) operands (bf16 engine): when a_scale is set, A [M][K] and W [N][K] are e4m3 bytes (lda / ldw in
     // elements), C = a_scale[m] * w_scale[n] * (A . W^T) then the usual epilogue in bf16; K % 16 == 0
