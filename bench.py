@@ -18,7 +18,7 @@ over all ranks (frame in -> action ids out).  `generate_boundary` is the same ru
 Extra objects on the JSON line:
   roofline      the gate/up SwiGLU GEMV of the decode step (largest single weight stream: 2*I*H*2 B = 271.6 MB per
                 launch, HBM-bound); `achieved` = those bytes / its mean duration, measured live with HIP events
-                on the engine's stream around the layer-0 launch of every decode step in the timed region.
+                on the engine's stream around the layer-0 launch of the first decode step of every turn in the timed region.
   cpu_baseline  the CPU oracle (fp32 port of the reference path, torch CPU, all host threads) on a bounded sample of
                 the same steady turn (rank 0, N = 1 only).
 """

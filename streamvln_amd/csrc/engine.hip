@@ -140,7 +140,7 @@ public:
     int n_feat_frames = 0;
     int* tap_idx; float* tap_w;
     // llm workspaces
-    T *x, *xn, *qkv, *attn, *hbuf, *hid_tap;
+    T *x, *xn, *qkv, *attn, *hbuf, *hid_tap, *head_xn;
     float* gemm_ws = nullptr; size_t gemm_ws_elems = 0; void* zero_line = nullptr;
     float* inv_freq; float* rope_tab;
     float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
@@ -293,6 +293,7 @@ public:
         const size_t rt = (size_t)c.max_positions;
         x = dalloc<T>(rt * H); xn = dalloc<T>(rt * H); qkv = dalloc<T>(rt * qkv_dim); attn = dalloc<T>(rt * qd); hbuf = dalloc<T>(rt * I);
         hid_tap = dalloc<T>((size_t)HID_TAP_ROWS * H);
+        head_xn = dalloc<T>((size_t)H);
         {   // split-K slabs: enough for 8 splits of the widest skinny product (rows of one ViT frame batch or a 512-row prefill)
             size_t widest = (size_t)(qkv_dim > 3 * Hv ? qkv_dim : 3 * Hv);
             if ((size_t)Iv > widest) widest = Iv;
@@ -814,10 +815,17 @@ public:
     // final norm -> hidden tap row -> lm_head arg-max -> d_token  (lm_head on the LAST position only).
     // `gen`: the arg-max also runs one step of the greedy loop on the device (GenCtl: append, EOS / max_new stop, advance the position)
     // and every launch is guarded by the done flag.
+    // With `gen` the tap row is GenCtl.count on the device (= tap_row on the host: tokens emitted so far), so the three launches are the
+    // same for every decode step and sit at the end of the captured step graph.
     void head(const T* xrow, int tap_row, bool gen) {
         T* tap = hid_tap + (size_t)(tap_row < HID_TAP_ROWS ? tap_row : HID_TAP_ROWS - 1) * H;
         const int* skip = gen ? &d_ctl->done : nullptr;
-        launch_rmsnorm<T>(st, xrow, final_norm, tap, 1, H, c.rms_eps, skip);
+        if (gen) {
+            launch_rmsnorm<T>(st, xrow, final_norm, head_xn, 1, H, c.rms_eps, skip, hid_tap, &d_ctl->count, HID_TAP_ROWS);
+            tap = head_xn;
+        } else {
+            launch_rmsnorm<T>(st, xrow, final_norm, tap, 1, H, c.rms_eps, skip);
+        }
         GemvArgs a = with8(gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX), lm_head8);
         a.skip = skip;
         launch_gemv<T>(st, a);
@@ -858,6 +866,7 @@ public:
         hipGraph_t g; hipGraphExec_t ex;
         HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         decode_ops(e, lo, hi);
+        if (hi == total_ops()) head(x, 0, true);       // (the tap row comes from the device)
         HIP_CHECK(hipStreamEndCapture(st, &g));
         HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphDestroy(g));
@@ -873,7 +882,9 @@ public:
     // for the GPU, so several steps can be in flight behind one another.
     void decode_step(Env& e, int env, int tap_row) {
         const int n_ops = total_ops();
-        const bool probing = probe_on && probe_used + 2 <= probe_ev.size();
+        // the roofline probe times the layer-0 gate/up GEMV of the FIRST decode step of every turn (a probed step runs as two graphs around a
+        // plain timed launch; the other steps replay the whole-step graph)
+        const bool probing = probe_on && tap_row == 1 && probe_used + 2 <= probe_ev.size();
         if (use_graph) {
             if (graph_env != env) {
                 drop_graphs();
@@ -889,14 +900,16 @@ public:
                 probe_launch(e);
                 HIP_CHECK(hipGraphLaunch(graph_exec[2], st));
             }
-        } else if (!probing) {
-            decode_ops(e, 0, n_ops);
         } else {
-            decode_ops(e, 0, PROBE_OP);
-            probe_launch(e);
-            decode_ops(e, PROBE_OP + 1, n_ops);
+            if (!probing) {
+                decode_ops(e, 0, n_ops);
+            } else {
+                decode_ops(e, 0, PROBE_OP);
+                probe_launch(e);
+                decode_ops(e, PROBE_OP + 1, n_ops);
+            }
+            head(x, tap_row, true);
         }
-        head(x, tap_row, true);
     }
 
     // ------------------------------------------------------------------------------- multi-env lockstep

@@ -144,7 +144,9 @@ template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, in
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);
 
 // RMSNorm / LayerNorm over rows of length n (T in, T out).
-template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip = nullptr);
+// y2 / y2_row / y2_cap: optional second copy of the rows at row *y2_row (device scalar) of y2, clamped to y2_cap rows
+template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip = nullptr,
+                                          void* y2 = nullptr, const int* y2_row = nullptr, int y2_cap = 0);
 template <typename T> void launch_layernorm(hipStream_t s, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps);
 
 // RoPE on q,k (in place on q) + append roped k and v to the paged cache.

@@ -11,8 +11,11 @@ namespace {
 
 // ------------------------------------------------------------------------------------------ norms
 // one wave per row; three cached passes (the row stays in L1/L2): statistics in fp32.
+// y2 (optional): a second copy of the normalised rows starting at row *y2_row (device scalar, clamped to y2_cap - 1) of y2 -- the hidden tap
+// of a decode step whose index only the device knows (GenCtl.count), so the launch can sit in a captured graph
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* g, T* y, int rows, int n, float eps, const int* skip) {
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* g, T* y, int rows, int n, float eps, const int* skip, T* y2,
+                                                      const int* y2_row, int y2_cap) {
     constexpr int EPC = Elt<T>::PER_CHUNK;
     if (skip && *skip) return;
     const int lane = threadIdx.x & 63;
@@ -36,7 +39,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* g, T*
         chunk_to_f32<T>(*(const uint4*)(g + (size_t)ci * EPC), gf);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) f[e] = gf[e] * (f[e] * sc);
-        *(uint4*)(yr + (size_t)ci * EPC) = f32_to_chunk<T>(f);
+        const uint4 o = f32_to_chunk<T>(f);
+        *(uint4*)(yr + (size_t)ci * EPC) = o;
+        if (y2) {
+            const int r2 = min(*y2_row + row, y2_cap - 1);
+            *(uint4*)(y2 + (size_t)r2 * n + (size_t)ci * EPC) = o;
+        }
     }
 }
 
@@ -324,9 +332,11 @@ int grid_for(int64_t n) {
 
 }  // namespace
 
-template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip) {
+template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip,
+                                          void* y2, const int* y2_row, int y2_cap) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (T*)y, rows, n, eps, skip);
+    hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (T*)y, rows, n, eps, skip, (T*)y2,
+                       y2_row, y2_cap);
 }
 template <typename T> void launch_layernorm(hipStream_t s, const void* x, const void* g, const void* b, void* y, int rows, int n, float eps) {
     if (rows <= 0) return;
@@ -390,7 +400,7 @@ template <typename T> void launch_from_f32(hipStream_t s, const float* src, void
 }
 
 #define SVLN_INST(T)                                                                                                              \
-    template void launch_rmsnorm<T>(hipStream_t, const void*, const void*, void*, int, int, float, const int*);                              \
+    template void launch_rmsnorm<T>(hipStream_t, const void*, const void*, void*, int, int, float, const int*, void*, const int*, int);                              \
     template void launch_layernorm<T>(hipStream_t, const void*, const void*, const void*, void*, int, int, float);               \
     template void launch_rope_kv<T>(hipStream_t, const RopeKvArgs&);                                                              \
     template void launch_vit_kv_pack<T>(hipStream_t, const void*, int, void*, void*, int, int, int, int);                         \
