@@ -62,6 +62,19 @@ def test_turn_protocol_matches_reference_loop():
     assert c[0]["do_sample"] is False and c[0]["num_beams"] == 1 and c[0]["use_cache"] is True
 
 
+def test_agent_keeps_ids_on_the_host_unless_asked():
+    """The engine reads token ids from the host: the agent does not send them through `device` (the reference callers do,
+    streamvln_eval.py:326; the model accepts both).  `ids_device=None` restores the reference placement."""
+    m = FakeModel()
+    ag = _agent(m, num_frames=8, num_future_steps=4, num_history=2, device="meta")
+    ag.observe(0)
+    req = ag._build_request("")
+    assert req["inputs"].device.type == "cpu" and req["images"].device.type == "meta"
+    ag2 = _agent(m, num_frames=8, num_future_steps=4, num_history=2, device="meta", ids_device=None)
+    ag2.observe(0)
+    assert ag2._build_request("")["inputs"].device.type == "meta"
+
+
 def test_step_flavour_window_reset():
     """streamvln_agent.py:169-258: run_model=False steps only record; reset when (step_id+1) % num_frames == 0"""
     m = FakeModel()
