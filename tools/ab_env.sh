@@ -11,6 +11,6 @@ for V in "$@"; do
   T=$(ls $OUT/*/*kernel_trace.csv | head -1)
   echo "== $VAR=$V  $(python3 -c "import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['p50_ms_per_turn'])")"
   python3 profiles/turn_breakdown.py $T 6 | head -3
-  python3 profiles/turn_breakdown.py $T 9 | head -3
+  python3 profiles/turn_breakdown.py $T 8 | head -3
   rm -rf $OUT
 done
