@@ -22,6 +22,8 @@
 // Roofline: MFMA for M >= ~512 (measured 770-990 TF/s, MFMA pipe busy ~45 %: one stage in flight per CU); at M ~ 212 the L2 -> LDS path
 // (t_stage ~ W_bytes / 6 TB/s + A_bytes / 22.7 TB/s).
 // Algorithmic flops = 2*M*N*K, algorithmic bytes = (M*K + N*K + M*N) * sizeof(T).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -261,7 +263,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // Ring of NBUF stage buffers, NBUF-1 stages in flight behind a counted s_waitcnt vmcnt + one raw s_barrier per stage:
 //   wait(stage i landed) ; barrier ; issue stage i+NBUF-1 into the buffer read in iteration i-1 ; MFMAs on stage i.
 // Rows beyond M / N are clamped to the last valid row (their outputs are never stored); K-tail chunks read a zero line.
-template <typename T, int EPI, typename C, bool SPLITK, typename TA = T>
+// NTW: the weight tile is staged with non-temporal LDS-DMA (products with ONE row tile: every weight byte is read once, by one workgroup).
+// A template parameter, not a run-time flag: a branch around the DMA issue of the large-tile kernels cost the window-restart prefill 2.5 ms.
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     constexpr int PER_WAVE = (BLK_A + BLK_W) / WAVES;
     constexpr int D = C::NBUF - 1;
     static_assert((BLK_A + BLK_W) % WAVES == 0, "blocks must divide over waves");
+    static_assert(!NTW || BLK_A % WAVES == 0, "NTW: a wave's blocks must be all-activation or all-weight per index");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / C::WN, wc = wave % C::WN;
     const int r32 = lane & 31, h = lane >> 5;
@@ -317,9 +322,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         for (int j = 0; j < PER_WAVE; ++j) {
             const char* g = src[j] + (size_t)st * C::ROWB;
             if (!full && st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
-            // weight blocks of a product with a single row tile (every weight byte is read once, by one workgroup): non-temporal, aux = 2
-            // (measured inside the turn: steady prefill 6.80 -> 6.63 ms; the activation panel, re-read by every workgroup, stays cached)
-            if (p.nt_w && wave + WAVES * j >= BLK_A) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
+            // NTW: the weight blocks (j >= BLK_A / WAVES for every wave) non-temporal, aux = 2 (measured inside the turn: steady prefill
+            // 6.80 -> 6.63 ms); the activation panel, re-read by every workgroup, stays cached
+            if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
             else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
         }
     };
@@ -738,9 +743,22 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
             return;
         }
     }
+    constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value;      // the single-row-tile configurations
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
+            if constexpr (HAS_NTW) {
+                if (a.nt_w) {
+                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+            return;
+        }
+    }
+    if constexpr (HAS_NTW) {
+        if (a.nt_w) {
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
             return;
         }
     }
@@ -900,6 +918,10 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, Cfg128::NBUF * Cfg128::STAGE_BYTES);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, Cfg64::NBUF * Cfg64::STAGE_BYTES);
@@ -909,6 +931,10 @@ template <typename T, int EPI> static void gemm_attr() {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false, fp8_t>, Cfg64::NBUF * Cfg64::STAGE_BYTES);
