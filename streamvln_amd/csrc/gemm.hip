@@ -318,10 +318,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     auto issue = [&](int st, int buf) {
         char* base = smem + buf * C::STAGE_BYTES;
         const bool full = (st + 1) * C::CH <= kchunks;
+        if (full) {                       // every stage but a ragged last one: no per-lane source select in front of the DMA instructions
+#pragma unroll
+            for (int j = 0; j < PER_WAVE; ++j) {
+                const char* g = src[j] + (size_t)st * C::ROWB;
+                if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
+                else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < PER_WAVE; ++j) {
             const char* g = src[j] + (size_t)st * C::ROWB;
-            if (!full && st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
+            if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
             // NTW: the weight blocks (j >= BLK_A / WAVES for every wave) non-temporal, aux = 2 (measured inside the turn: steady prefill
             // 6.80 -> 6.63 ms); the activation panel, re-read by every workgroup, stays cached
             if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
@@ -390,9 +399,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         for (int j = 0; j < NJ; ++j)
             if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
     };
-    auto compute = [&](int buf) {
+    // after_first_reads: the DMA issue of a later stage, placed behind the first fragment reads of this one so that its address arithmetic
+    // (8 loads x ~8 VALU + the m0 set-up per wave, all waves at once right after the barrier) runs under their LDS latency
+    auto compute = [&](int buf, auto&& after_first_reads) {
         const unsigned bo = buf * C::STAGE_BYTES;
         read_step(0, bo);
+        after_first_reads();
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             if (INTERLEAVE) {
@@ -434,8 +446,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         if (i + D <= n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (i + D < n) issue(st_begin + i + D, nbuf);
-        compute(buf);
+        compute(buf, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
     }
