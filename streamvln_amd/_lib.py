@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SVLN_LIB_AB") or os.path.join(_HERE, "libstreamvln_hip.so")
+LIB_PATH = os.path.join(_HERE, "libstreamvln_hip.so")
 
 SVLN_BF16, SVLN_F32 = 0, 1
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_SWIGLU, EPI_ARGMAX = 0, 1, 2, 3, 4
