@@ -546,11 +546,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 
 // merge split-KV partials: one wave per (kh, rho).  Pass 1: lane z owns split z (m_z, l_z) -> wave max / weights;
 // pass 2: lane d owns output channels d and d + 64 and sums the weighted partial rows (independent loads).
+// A wave per row; four rows per workgroup when there are many rows (prefill / ViT: thousands of single-wave workgroups are dispatch-bound),
+// one row per workgroup for the few rows of a decode step (spread over as many CUs as possible: 5.8 us against 9.4 with four per workgroup).
 template <typename T, int HD>
-__global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
-    __shared__ float wsh[64];
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p) {
+    __shared__ float wsh_all[4][64];
     if (p.skip && *p.skip) return;
-    const int rho = blockIdx.x, kh = blockIdx.y, env = blockIdx.z, lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* wsh = wsh_all[wave];         // written and read by this wave only
+    const int rho = blockIdx.x * (blockDim.x >> 6) + wave, kh = blockIdx.y, env = blockIdx.z;
+    if (rho >= p.T * p.G) return;
     const int kv_len = p.slots ? p.slots[env].pos + 1 : (p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len);
     const int tiles = (kv_len + 63) >> 6;
     const int nsplit = min(min(p.nsplit, 64), (tiles + p.tiles_per_split - 1) / p.tiles_per_split);
@@ -561,12 +566,12 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(AttnArgs p) {
     const float mstar = wave_max(mz);
     const float w = mz == -INFINITY ? 0.0f : fast_exp2(mz - mstar);      // m values are in the log2 domain
     const float lsum = wave_sum(w * lz);
-    wsh[lane] = w;
-    __syncthreads();
+    wsh[lane] = w;                      // (LDS executes a wave's accesses in order: no workgroup barrier, and the rows that returned above never reach one)
+    __builtin_amdgcn_wave_barrier();
     float o0 = 0.0f, o1 = 0.0f;
     for (int z = 0; z < nsplit; ++z) {
         const float* pz = base + z * split_stride;
-        const float wz = wsh[z];
+        const float wz = wsh[z];        // (a v_readlane per split instead measured 9.4 us against 5.8 on the decode merge: it serialises the loads)
         if (lane < HD) o0 += wz * pz[lane];
         if (lane + 64 < HD) o1 += wz * pz[lane + 64];
     }
@@ -601,7 +606,8 @@ template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, in
     }
 }
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim) {
-    dim3 grid(a.T * a.G, a.n_kv_total, a.batch > 0 ? a.batch : 1), block(64);
+    const int rows = a.T * a.G, rpw = rows >= 256 ? 4 : 1;
+    dim3 grid((rows + rpw - 1) / rpw, a.n_kv_total, a.batch > 0 ? a.batch : 1), block(64 * rpw);
     if (head_dim == 128) hipLaunchKernelGGL((attn_combine_kernel<T, 128>), grid, block, 0, s, a);
     else if (head_dim == 72) hipLaunchKernelGGL((attn_combine_kernel<T, 72>), grid, block, 0, s, a);
 }

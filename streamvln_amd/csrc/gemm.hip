@@ -644,11 +644,12 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
 
 // Split-K reduce of the prefill QKV product fused with its tail (modeling_qwen2.py:195-235): C = round(sum_s slab + bias), RoPE on the
 // q and k heads (cos / sin table, rotate_half), q back into C, roped k and v^T appended to the paged KV cache -- splitk_epilogue_kernel
-// followed by rope_kv_kernel in one pass (same arithmetic, same intermediate rounding to T).  grid (rows, nq + 2 nkv heads), 64 threads:
-// lane d owns columns d and d + 64 of a 128-wide head.
+// followed by rope_kv_kernel in one pass (same arithmetic, same intermediate rounding to T).  grid (rows, ceil((nq + 2 nkv) / 4)), 256 threads:
+// a wave per head, lane d owns columns d and d + 64 of the 128-wide head.
 template <typename T>
-__global__ __launch_bounds__(64) void splitk_qkv_rope_kernel(GemmArgs p, RopeKvArgs r) {
-    const int i = blockIdx.x, hd = blockIdx.y, d = threadIdx.x;
+__global__ __launch_bounds__(256) void splitk_qkv_rope_kernel(GemmArgs p, RopeKvArgs r) {
+    const int i = blockIdx.x, hd = blockIdx.y * 4 + (threadIdx.x >> 6), d = threadIdx.x & 63;      // a wave per head, four heads per workgroup
+    if (hd >= r.nq + 2 * r.nkv) return;
     const size_t slab = (size_t)p.M * p.N;
     const int c0 = hd * 128 + d;
     const float* src = p.ws + (size_t)i * p.N + c0;
@@ -792,7 +793,7 @@ template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_
         return true;
     }
     if (EPI == EPI_NONE && a.rope && a.tile_base == 0 && !a.res && a.N == (a.rope->nq + 2 * a.rope->nkv) * 128 && a.M == a.rope->T) {
-        hipLaunchKernelGGL((splitk_qkv_rope_kernel<T>), dim3(a.M, a.N / 128), dim3(64), 0, s, a, *a.rope);
+        hipLaunchKernelGGL((splitk_qkv_rope_kernel<T>), dim3(a.M, (a.N / 128 + 3) / 4), dim3(256), 0, s, a, *a.rope);
         return true;
     }
     const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
