@@ -87,9 +87,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const T* g, 
 // --------------------------------------------------------------------------------- RoPE + KV append
 // grid (T, nq + nkv + nkv), 64 threads: lane d pairs (d, d + 64) of a 128-wide head.
 // q heads: rotate in place.  k heads: rotate, write K page row.  v heads: write transposed Vt page.
+// A wave per (row, head), four heads per workgroup (70 000 single-wave workgroups at T = 1952 are dispatch-bound).
 template <typename T>
-__global__ __launch_bounds__(64) void rope_kv_kernel(RopeKvArgs p) {
-    const int i = blockIdx.x, hd = blockIdx.y, d = threadIdx.x;
+__global__ __launch_bounds__(256) void rope_kv_kernel(RopeKvArgs p) {
+    const int i = blockIdx.x, hd = blockIdx.y * 4 + (threadIdx.x >> 6), d = threadIdx.x & 63;
+    if (hd >= p.nq + 2 * p.nkv) return;
     const int P = p.dyn_pos ? *p.dyn_pos : p.P;
     const int pos = P + i;
     T* row = (T*)p.qkv + (size_t)i * p.ld + (size_t)hd * 128;
@@ -343,7 +345,7 @@ template <typename T> void launch_layernorm(hipStream_t s, const void* x, const 
     hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, (const T*)g, (const T*)b, (T*)y, rows, n, eps);
 }
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a) {
-    hipLaunchKernelGGL((rope_kv_kernel<T>), dim3(a.T, a.nq + 2 * a.nkv), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((rope_kv_kernel<T>), dim3(a.T, (a.nq + 2 * a.nkv + 3) / 4), dim3(256), 0, s, a);
 }
 void launch_frame_hash(hipStream_t s, const float* pix, int F, size_t words_per_frame, unsigned long long* out) {
     hipLaunchKernelGGL(frame_hash_kernel, dim3(64, F), dim3(256), 0, s, (const uint32_t*)pix, words_per_frame, out);
