@@ -820,8 +820,9 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     //   M  > 256, >= 256 tiles of 128x128 (a full round at two workgroups per CU) -> 128x128 tiles, no split
     //   otherwise (less than a round of 128x128 tiles: every one-frame ViT product, o/down at T = 376) -> 256x128 tiles + split-K: inside the
     //   turn the K-split launch + reduce beats the half-empty unsplit launch (one-frame ViT fc1: 16.8 + 10.0 us against 31.4; qkv equal)
-    //   large M AND N (>= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
-    //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel
+    //   large M AND N (M > 512 and >= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
+    //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel.  With two row tiles (the 376-row first turn of an
+    //   episode) the second one is mostly padding: 128x128 tiles take its gate/up from 192 to ~140 us (prefill of that turn 10.5 -> 9.0 ms)
     // M <= 32 (several envs decoded in lockstep): 32x128 tiles, 2 waves, three 20 KB stages in flight per workgroup and two
     // workgroups per CU -- a weight stream through LDS-DMA with 4 MFMAs per stage, K split when there are few column tiles
     if (a.M <= 32 && a.zeros && !(a.force_cfg & 0x2000) && ((a.force_cfg & 0xFFF) == 0 || (a.force_cfg & 0xFFF) == 32)) {
@@ -841,7 +842,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         return launch_split<T, EPI, CfgSkinny>(s, a, S);
     }
     const int tilesbig = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if ((tilesbig >= 256 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
+    if ((tilesbig >= 256 && a.M > 512 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
         a.nsplit = 1;
         a.launch_tiles = tilesbig;
         launch_cfg<T, EPI, CfgBig, false>(s, a, 1);
