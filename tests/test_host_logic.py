@@ -275,3 +275,35 @@ def test_run_sharded_resumes_by_skipping_finished_episodes(tmp_path):
     ran.clear()
     again = run_sharded(eps, lambda s, e: run_episode(s, e, limit=[99]), result_path=path)                         # nothing left to do
     assert ran == [] and again["length"] == 6
+
+
+def test_oracle_is_test_infrastructure_only():
+    """`oracle/` may be imported by tests/, by `__graft_entry__.smoke()` and by bench.py's `cpu_baseline*` functions -- nowhere in the product
+    package, not in the timed part of bench.py, not in tools/ (checked on the syntax tree: an import inside any other function or at module
+    level fails)."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read(), path)
+        hits = []
+
+        def visit(node, fn):
+            for child in ast.iter_child_nodes(node):
+                name = fn
+                if isinstance(child, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                    name = child.name if fn is None else fn            # the outermost enclosing function
+                if isinstance(child, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in child.names):
+                    hits.append(fn)
+                if isinstance(child, ast.ImportFrom) and (child.module or "").split(".")[0] == "oracle":
+                    hits.append(fn)
+                visit(child, name)
+        visit(tree, None)
+        return hits
+
+    for path in glob.glob(os.path.join(root, "streamvln_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(root, "tools", "*.py")):
+        assert oracle_imports(path) == [], path
+    assert all(fn and fn.startswith("cpu_baseline") for fn in oracle_imports(os.path.join(root, "bench.py")))
+    assert all(fn == "smoke" for fn in oracle_imports(os.path.join(root, "__graft_entry__.py")))
+    assert oracle_imports(os.path.join(root, "bench.py")) and oracle_imports(os.path.join(root, "__graft_entry__.py"))
