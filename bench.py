@@ -2,7 +2,11 @@
 """bench.py -- action-steps/s of the StreamVLN streaming-inference hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...: RANK /
+  LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or as the plain command above: without RANK in the environment
+  bench.py starts that launcher itself as a CHILD process (before anything here has touched the GPU), relays rank 0's JSON line and
+  exits with the child's return code -- the reference's `torchrun --nproc_per_node=8 streamvln/streamvln_eval.py`
+  (scripts/streamvln_eval_multi_gpu.sh:7) as one command.
 
 Workload (BASELINE.json configs[1]): StreamVLN-Qwen-1.5 = SigLIP-so400m + Qwen2-7B at true
 size, bf16, seeded random-init weights, synthetic 640x480 RGB stream, 8-frame window
@@ -33,9 +37,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -56,6 +57,34 @@ def parse():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`bench.py --gpus N` (N > 1) started without a launcher: run `python -m torch.distributed.run ... bench.py <same args>` as a child
+    process, one rank per GPU, and pass its output and return code through.  Nothing in this process has initialised the GPU (no HIP
+    call, no torch.cuda query) and nothing is exec'd: the child is an ordinary subprocess."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    r = subprocess.run(cmd, env=env, cwd=ROOT)          # the ranks inherit stdout / stderr: rank 0 prints the ONE JSON line
+    return r.returncode
+
+
+if __name__ == "__main__":
+    # N > 1 without a launcher: hand over to the child launcher BEFORE importing torch (nothing here has touched the GPU)
+    _a = parse()
+    if _a.gpus > 1 and ("RANK" not in os.environ or "WORLD_SIZE" not in os.environ):
+        sys.exit(self_launch(_a))
+
+import numpy as np
+import torch
 
 
 NUM_FRAMES, NUM_FUTURE, NUM_HISTORY, EP_STEPS, DECODE_TOKENS = 32, 4, 8, 64, 5
@@ -107,8 +136,9 @@ def timed_pass(model, turn, steps, warmup, world, lat=None):
     import torch.distributed as dist
     for _ in range(warmup):
         turn()
+    grouped = dist.is_initialized()      # (a 1-rank group still runs the barrier / all-reduce: the RCCL branch on a one-GPU box)
     model.sync(); torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -117,10 +147,10 @@ def timed_pass(model, turn, steps, warmup, world, lat=None):
         if lat is not None:
             lat.append(time.perf_counter() - t1)
     model.sync(); torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -397,7 +427,7 @@ def main():
                                             "weight and activation scales, fp32 accumulate, bf16 out); lm_head, attention, vision bf16",
                                    "note": "opt-in extension, no reference counterpart; reduced precision, never the headline"}
     # the one exchange of the path: per-episode metrics -> 5-scalar RCCL all-reduce (synthetic metrics here)
-    summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+    summary = reduce_metrics([{"success": 1.0, "spl": 0.5, "os": 1.0, "ne": float(rank)}], device="cuda" if (dist.is_initialized() and dist.get_backend() == "nccl") else "cpu")
     turns_total = a.steps * world
     value = NUM_FUTURE * turns_total / dt
     if rank == 0:
@@ -409,7 +439,8 @@ def main():
                                    "8-frame window (num_frames 32 / future 4 / history 8), 5 decode tokens/turn, 1 env per GPU; "
                                    "step = one model turn = 4 env steps, each preprocessing its frame (upload + HIP bicubic) inside "
                                    "the timed region", "model_config": a.config, "envs_per_gpu": 1,
-                       "decode_graph": not a.no_graph, "parallelism": f"episode-parallel x{world}"},
+                       "decode_graph": not a.no_graph, "parallelism": f"episode-parallel x{world}",
+                       "dist_backend": dist.get_backend() if dist.is_initialized() else None},
             "per_gpu": round(value / world, 2),
             "p50_ms_per_turn": round(float(np.median(lat)) * 1e3, 3),
             "turn_ms": [round(x * 1e3, 2) for x in lat],
@@ -435,7 +466,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(CONFIGS["streamvln_qwen2_7b"])
         print(json.dumps(out), flush=True)
     model.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -62,7 +62,7 @@ def reduce_metrics(per_episode: List[Dict[str, float]], device: torch.device | s
     {sucs_all, spls_all, oss_all, ones_all, length} (streamvln_eval.py:570-576)."""
     n = len(per_episode)
     cols = {k: [float(m[k]) for m in per_episode] for k in METRIC_KEYS}
-    if not is_dist_avail_and_initialized() or get_world_size() == 1:
+    if not is_dist_avail_and_initialized():
         sums = {k: sum(v) for k, v in cols.items()}
         total = n
     elif mode == "all_reduce":

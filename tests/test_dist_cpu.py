@@ -57,3 +57,20 @@ def test_world_size_2_gloo():
     for mode in ("all_reduce", "all_gather"):
         for k, v in exp.items():
             assert abs(out[mode][k] - v) < 1e-12, (mode, k, out[mode][k], v)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK in the environment starts `torch.distributed.run` as a child process and passes its
+    return code through (the GPU box runs the same command to completion: tests/test_dist_gpu.py).  Without a GPU both ranks get past
+    the rendezvous and the WORLD_SIZE check and stop at the 'needs a GPU' assertion; the parent must report that failure, not
+    'WORLD_SIZE 1'."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--config",
+                        "tiny", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    import torch
+    if torch.cuda.is_available():       # on a GPU box the run completes
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    assert r.returncode != 0
+    assert "WORLD_SIZE 1" not in r.stderr
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]          # both ranks were started and initialised gloo
