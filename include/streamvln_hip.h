@@ -65,7 +65,11 @@ int svln_encode_frames(svln_engine* h, const float* pixels, int n_frames, int on
 int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev);
 /* The same work without the final wait: returns once the frame bytes have been consumed (copied to pinned staging) and the upload +
  * kernel are enqueued on the engine's stream.  svln_encode_frames / svln_generate on the same engine are ordered behind it; any other
- * stream that touches out_dev must first wait on the engine's stream (svln_engine_stream: the hipStream_t as a void*). */
+ * stream that touches out_dev must first wait on the engine's stream (svln_engine_stream: the hipStream_t as a void*).
+ * Lifetime of rgb: with on_device = 0 the bytes have been copied when the call returns and the caller may reuse the buffer.  With
+ * on_device = 1 the engine's stream reads the caller's DEVICE buffer asynchronously: it must stay allocated and unmodified until the
+ * work enqueued here has run (wait on svln_engine_stream, or call svln_sync), and whatever stream produced it must have finished --
+ * or the engine's stream must have been ordered behind it -- before this call. */
 int svln_preprocess_frames_enqueue(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev);
 int svln_engine_stream(svln_engine* h, void** stream);
 int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset);
@@ -75,12 +79,22 @@ int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int re
  * of the last svln_encode_frames call form the memory block, the rest are consumed by <image> in order.
  * Rows are appended to the env's inputs_embeds (stream_video_vln.py:396-401). */
 int svln_append_turn(svln_engine* h, int env, const int64_t* ids, int n_ids, int n_memory);
+/* config.tokenizer_model_max_length of the reference (stream_video_vln.py:241-244): the spliced rows of ONE turn are truncated to
+ * `rows` before they are appended (new_input_embeds[:tokenizer_model_max_length]).  0 = no truncation (the attribute is None, the
+ * reference's default).  Independent of max_positions, the capacity of the accumulated sequence, which the reference does not have:
+ * exceeding it is an error ("inputs_embeds exceeds max_positions"). */
+int svln_set_turn_row_limit(svln_engine* h, int rows);
 
 /* -- greedy generation: StreamVLNForCausalLM.generate -> GenerationMixin (do_sample=False, num_beams=1):
  * prefill embeds[kv_len:], arg-max, feed generated ids until one is in eos_ids (appended, not fed) or
  * max_new_tokens; afterwards kv_len = n_embeds + n_out - 1. */
 int svln_generate(svln_engine* h, int env, int max_new_tokens, const int64_t* eos_ids, int n_eos, int64_t* out_ids,
                   int out_cap, int32_t* n_out);
+/* generation_config.repetition_penalty of a checkpoint: transformers' RepetitionPenaltyLogitsProcessor -- applied by
+ * GenerationMixin under greedy decoding too -- on the fp32 logits of every step, over the ids generated so far in the turn (the prompt is
+ * passed as inputs_embeds, so it has no ids): logit < 0 ? logit * penalty : logit / penalty.  1 = off (default).  Applies to svln_generate,
+ * svln_generate_batch and the scheduler; cannot change while scheduler turns are in flight. */
+int svln_set_repetition_penalty(svln_engine* h, float penalty);
 /* perf harness variant: decode exactly n_tokens regardless of EOS */
 int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out_ids);
 
@@ -102,6 +116,10 @@ int svln_generate_batch(svln_engine* h, const int32_t* envs, int n_envs, int max
 int svln_batch_submit(svln_engine* h, int env, int max_new_tokens, const int64_t* eos_ids, int n_eos, int32_t* slot);
 int svln_batch_step(svln_engine* h, int32_t* running, int32_t* finished_slots, int32_t* n_finished);
 int svln_batch_result(svln_engine* h, int slot, int32_t* env, int64_t* out_ids, int out_cap, int32_t* n_out);
+/* Drop the turn in `slot` (slot < 0: every turn in flight), finished or not; its slot is free again.  svln_reset_env / svln_kv_reset drop
+ * the env's turn themselves.  A svln_batch_step that fails part-way drops every turn in flight before it returns the error (a turn whose
+ * env has no rows left to prefill is dropped alone), so the scheduler is always usable after an error. */
+int svln_batch_cancel(svln_engine* h, int slot);
 int svln_get_hidden_batch(svln_engine* h, int slot, float* host_out, int max_rows, int32_t* n_rows);   /* parity tap, <= 8 rows */
 
 /* -- parity taps (test infrastructure reads these; not used by the product path) */

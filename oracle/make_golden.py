@@ -15,6 +15,10 @@ Scenarios
                  step 32 (9 views, 1568-row <memory> block, T=1952); decode capped at 3 tokens.
   true4_episode  true dimensions, 4 ViT + 4 LLM layers, FULL vocabulary 152 064: first turn + one
                  steady turn, 4 tokens each (inter-layer fused norms, full-size lm_head / arg-max).
+  tiny_truncate  TINY, config.tokenizer_model_max_length = 150: the reference truncates every turn's spliced rows
+                 (stream_video_vln.py:241-244).
+  tiny_penalty   TINY, generation_config.repetition_penalty = 1.3 through transformers' own
+                 RepetitionPenaltyLogitsProcessor in the restated 4.45.1 greedy loop.
 Usage: python -m oracle.make_golden [scenario ... | preprocess]   (default: everything)
 Each scenario is driven through the same `StreamingAgent` twice (reference, oracle); the
 script asserts ids equal and hidden/features within 2e-4 abs+rel before writing.
@@ -38,7 +42,7 @@ from oracle import streamvln_oracle as O                      # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from scenarios import SCENARIOS, SEED, run_scenario            # noqa: E402
+from scenarios import SCENARIOS, SEED, apply_knobs, run_scenario            # noqa: E402
 
 
 class _RefOut:
@@ -127,6 +131,8 @@ def main():
         ref = RH.build_reference_model(cfg, sd, sc["num_history"])
         ref.reset(1)
         orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"])
+        apply_knobs(ref, sc)
+        apply_knobs(orc, sc)
         log_r, emb_r = run(RefAdapter(ref), sc, lambda out: out.embeds)
         # oracle: per-turn embeds = the rows appended to its cache this turn
         seen = [0]

@@ -129,10 +129,20 @@ def reference_turn(model, env_id, inputs, images, time_ids, past, max_new_tokens
         h = o.last_hidden_state[0, -1]
         return h, model.lm_head(h)
 
+    # generation_config.repetition_penalty: GenerationMixin._get_logits_processor adds transformers' own
+    # RepetitionPenaltyLogitsProcessor (greedy included); its input_ids are the generated ids only (the prompt is inputs_embeds)
+    pen = float(getattr(model.generation_config, "repetition_penalty", None) or 1.0)
+    proc = None
+    if pen != 1.0:
+        from transformers import RepetitionPenaltyLogitsProcessor
+        proc = RepetitionPenaltyLogitsProcessor(penalty=pen)
     h, logits = fwd(inputs_embeds=E[:, P:])
     out, hid = [], []
     while True:
-        tok = int(torch.argmax(logits.float()))
+        scores = logits.float()
+        if proc is not None and out:
+            scores = proc(torch.tensor([out], dtype=torch.long), scores[None].clone())[0]
+        tok = int(torch.argmax(scores))
         out.append(tok); hid.append(h.clone())
         if tok in eos or len(out) >= max_new_tokens:
             break

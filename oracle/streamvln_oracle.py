@@ -12,9 +12,12 @@ What it restates (reference file:line under /root/reference unless noted):
   mm_projector          llava/model/multimodal_projector/builder.py:41-48 (Linear-GELU(erf)-Linear)
   get_2dPool            streamvln/model/stream_video_vln.py:53-73 (bilinear, align_corners=False)
   encode_rgbd           stream_video_vln.py:102-142
-  token splice          stream_video_vln.py:144-291 (batch of one env)
+  token splice          stream_video_vln.py:144-291 (batch of one env; :241-244 per-turn truncation to
+                        config.tokenizer_model_max_length)
   turn protocol         stream_video_vln.py:353-479 + transformers 4.45.1 GenerationMixin
                         (greedy; cache_position = arange(L_total)[P:])
+  repetition penalty    transformers RepetitionPenaltyLogitsProcessor (third-party, generation/logits_process.py;
+                        GenerationMixin applies generation_config.repetition_penalty under greedy decoding too)
   Qwen2 decoder         transformers Qwen2 equations (third-party, pinned 4.45.1 in the
                         reference's requirements.txt:140; same math as the container copy
                         transformers/models/qwen2/modeling_qwen2.py:35-48,91-135,150-173,238-252,269-299)
@@ -302,6 +305,19 @@ def lm_logits(w: W, h_last: torch.Tensor) -> torch.Tensor:
     return h_last @ w["lm_head.weight"].t()
 
 
+def repetition_penalty(logits: torch.Tensor, generated: Sequence[int], penalty: float) -> torch.Tensor:
+    """transformers RepetitionPenaltyLogitsProcessor.__call__ (third-party; pinned 4.45.1 in requirements.txt:140, same formula in the
+    container's copy): score = gather(scores, input_ids); score = where(score < 0, score * penalty, score / penalty); scatter back.
+    `generated` = the ids produced so far in this turn (the prompt enters as inputs_embeds and has no ids)."""
+    if penalty == 1.0 or not generated:
+        return logits
+    out = logits.clone()
+    idx = torch.tensor(sorted(set(int(t) for t in generated)), dtype=torch.long)
+    sc = out[idx]
+    out[idx] = torch.where(sc < 0, sc * penalty, sc / penalty)
+    return out
+
+
 def greedy_pick(logits: torch.Tensor):
     """argmax with lowest-index tie break (torch.argmax on CPU) + top-2 margin."""
     top2 = torch.topk(logits, 2)
@@ -324,7 +340,11 @@ class OracleStreamVLN:
     (reset / reset_for_env / generate), computing everything in fp32 on the CPU."""
 
     def __init__(self, cfg, weights: Dict[str, np.ndarray], num_history: Optional[int] = None, memory_keep: int = 0):
+        from types import SimpleNamespace
         self.cfg = cfg
+        # the two call-time knobs of the reference, under the reference's attribute names
+        self.config = SimpleNamespace(tokenizer_model_max_length=None)          # stream_video_vln.py:241
+        self.generation_config = SimpleNamespace(repetition_penalty=1.0)        # GenerationConfig default
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in weights.items()}
         self.num_history = num_history
         self.memory_keep = memory_keep          # > 0: opt-in extension prune_memory_tokens (no reference counterpart)
@@ -350,6 +370,9 @@ class OracleStreamVLN:
         if mem is not None and 0 < self.memory_keep < mem.shape[0]:
             mem = mem[prune_memory_tokens(mem, self.memory_keep)[0]]
         new = splice_embeds(w, ids, img, mem)
+        tml = getattr(self.config, "tokenizer_model_max_length", None)
+        if tml is not None:                                  # stream_video_vln.py:241-244: new_input_embeds[:tokenizer_model_max_length]
+            new = new[:tml]
         st = self.cache[env_id]
         st["inputs_embeds"] = new if self.curr_t[env_id] == 0 else torch.cat((st["inputs_embeds"], new), 0)
         self.curr_t[env_id] += 1
@@ -360,8 +383,9 @@ class OracleStreamVLN:
         eos = set(int(e) for e in eos_token_ids)
         h = qwen2_forward(w, cfg, E[P:], P, cache)[-1]
         out, hid, margins = [], [], []
+        pen = float(getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0)
         while True:
-            tok, margin = greedy_pick(lm_logits(w, h))
+            tok, margin = greedy_pick(repetition_penalty(lm_logits(w, h), out, pen))
             out.append(tok); hid.append(h.clone()); margins.append(margin)
             if tok in eos or len(out) >= max_new_tokens:
                 break

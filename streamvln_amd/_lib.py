@@ -52,6 +52,9 @@ SIGNATURES = {
     "svln_batch_submit": (_I, [_P, _I, _I, _PI64, _I, _PI32]),
     "svln_batch_step": (_I, [_P, _PI32, _PI32, _PI32]),
     "svln_batch_result": (_I, [_P, _I, _PI32, _PI64, _I, _PI32]),
+    "svln_batch_cancel": (_I, [_P, _I]),
+    "svln_set_turn_row_limit": (_I, [_P, _I]),
+    "svln_set_repetition_penalty": (_I, [_P, _F]),
     "svln_get_hidden_batch": (_I, [_P, _I, _PF, _I, _PI32]),
     "svln_generate": (_I, [_P, _I, _I, _PI64, _I, _PI64, _I, _PI32]),
     "svln_generate_fixed": (_I, [_P, _I, _I, _PI64]),

@@ -81,6 +81,9 @@ struct EngineBase {
     virtual int batch_submit(int env, int max_new, const int64_t* eos, int n_eos) = 0;
     virtual int batch_step(int32_t* finished_slots, int32_t* n_finished) = 0;
     virtual void batch_result(int slot, int32_t* env, int64_t* out, int cap, int32_t* n_out) = 0;
+    virtual void batch_cancel(int slot) = 0;
+    virtual void set_turn_row_limit(int rows) = 0;
+    virtual void set_repetition_penalty(float penalty) = 0;
     virtual void get_hidden_batch(int slot, float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_hidden(float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_embeds(int env, int start, int n, float* out) = 0;
@@ -168,9 +171,17 @@ public:
     std::vector<int> free_pages;
     int n_generated = 0;
 
-    // decode graph + probes
+    // decode graph + probes.  The step graph holds the env's page-table pointer, so there is one set per env (a round-robin over several
+    // envs through svln_generate replays instead of re-capturing); [0] = the whole step, [1] / [2] = the halves around the probed launch
+    // (captured only while the roofline probe is on).
     bool use_graph = false;
-    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr}; int graph_env = -1;
+    struct GraphSet { hipGraphExec_t ex[3] = {nullptr, nullptr, nullptr}; };
+    std::vector<GraphSet> graphs;
+    // per-turn truncation of the spliced rows (the reference's config.tokenizer_model_max_length, stream_video_vln.py:241-244); 0 = none
+    int turn_row_limit = 0;
+    // HF repetition penalty of the checkpoint's generation_config (1 = off): flags of the tokens generated in the current turn
+    float rep_penalty = 1.0f; uint8_t* pen_flags = nullptr; uint8_t* pen_flags_b = nullptr; int* d_pen_rows = nullptr; int* h_pen_rows = nullptr;
+    int* d_pen_ids = nullptr; int* h_pen_ids = nullptr;
     std::vector<hipEvent_t> probe_ev; size_t probe_used = 0; bool probe_on = false; double probe_bytes = 0;
     // second probe: the layer-0 gate/up product of every steady prefill (M <= 256 rows: main launch + K-split tail + reduce) between two events
     std::vector<hipEvent_t> pprobe_ev; size_t pprobe_used = 0; double pprobe_rows = 0;
@@ -336,6 +347,7 @@ public:
         HIP_CHECK(hipHostMalloc((void**)&h_token, 16));
         HIP_CHECK(hipHostMalloc((void**)&h_top2, 16));
         envs.resize(c.max_envs);
+        graphs.resize(c.max_envs);
         for (auto& e : envs) {
             e.embeds = dalloc<T>(rt * H);
             e.d_pages = dalloc<int>(pages_per_env, true);
@@ -354,6 +366,7 @@ public:
         (void)hipStreamSynchronize(st);
         drop_graphs();
         if (d_rgb) (void)hipFree(d_rgb);
+        for (auto& t : rs_tabs) for (void* p : t.bufs) (void)hipFree(p);
         for (int i = 0; i < 2; ++i) {
             if (h_rgb[i]) (void)hipHostFree(h_rgb[i]);
             if (h2d_ev[i]) (void)hipEventDestroy(h2d_ev[i]);
@@ -369,6 +382,8 @@ public:
         (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
         if (h_sel) (void)hipHostFree(h_sel);
         (void)hipHostFree(h_slots); (void)hipHostFree(h_tok_b);
+        if (h_pen_rows) (void)hipHostFree(h_pen_rows);
+        if (h_pen_ids) (void)hipHostFree(h_pen_ids);
         (void)hipStreamDestroy(st);
         if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
@@ -427,8 +442,10 @@ public:
         for (int i = 0; i < e.n_pages; ++i) free_pages.push_back(e.pages[i]);
         e.n_pages = 0;
     }
-    void reset_env(int env) override { Env& e = env_at(env); release_pages(e); e.n_embeds = 0; e.kv_len = 0; }
-    void kv_reset(int env) override { Env& e = env_at(env); release_pages(e); e.kv_len = 0; }
+    // A reset drops the env's turn in the multi-env scheduler, if it has one (submitted, running or finished but not collected): its rows
+    // and KV pages are gone, so the job must not reach another batch_step.
+    void reset_env(int env) override { Env& e = env_at(env); cancel_jobs_of(env); release_pages(e); e.n_embeds = 0; e.kv_len = 0; }
+    void kv_reset(int env) override { Env& e = env_at(env); cancel_jobs_of(env); release_pages(e); e.kv_len = 0; }
     void env_state(int env, int32_t* n_embeds, int32_t* kv_len) override { Env& e = env_at(env); *n_embeds = e.n_embeds; *kv_len = e.kv_len; }
     void ensure_pages(Env& e, int positions) {      // pages covering [0, positions)
         const int need = (positions + PAGE - 1) / PAGE;
@@ -583,7 +600,7 @@ public:
     // ------------------------------------------------------------------------------- a-1: image preprocess on the GPU
     // SigLipImageProcessor.preprocess (siglip_encoder.py:47-67), bit-exact with Pillow's bicubic (preprocess.hip).  Coefficient tables
     // are built on the host per frame geometry (double precision, Pillow's operation order) and cached on the device.
-    struct ResampleTabs { int H, W; ResampleDev dev; };
+    struct ResampleTabs { int H, W; ResampleDev dev; uint64_t stamp = 0; std::vector<void*> bufs; };
     std::vector<ResampleTabs> rs_tabs;
     uint8_t* d_rgb = nullptr; size_t d_rgb_cap = 0; float* d_lut = nullptr;
     // pinned staging, double-buffered: call i + 1 copies its frame in while the DMA of call i may still be reading the other buffer
@@ -604,18 +621,34 @@ public:
     }
     void pp_collect() { while (pp_tail < pp_head) pp_resolve_oldest(); }
     void* stream_handle() override { return (void*)st; }
+    // Coefficient tables per frame geometry: at most RS_CACHE geometries stay on the device (least recently used one evicted, its buffers
+    // reused by hipFree after a stream sync), and a geometry the kernel cannot take is rejected BEFORE anything is uploaded.
+    static constexpr int RS_CACHE = 4;
+    uint64_t rs_clock = 0;
     const ResampleDev& resample_tabs(int Hh, int Ww) {
-        for (auto& t : rs_tabs) if (t.H == Hh && t.W == Ww) return t.dev;
+        for (auto& t : rs_tabs) if (t.H == Hh && t.W == Ww) { t.stamp = ++rs_clock; return t.dev; }
         const int Sx = c.v_image;
         ResampleAxis ah, av;
         build_resample_table(Ww, Sx, ah);
         build_resample_table(Hh, Sx, av);
+        REQUIRE(av.ksize <= 40, "frame too large for the GPU preprocess kernel (more than 40 source rows per output row)");
+        REQUIRE(preprocess_lds_bytes(Ww, Sx, av.ksize, ah.ksize) <= (size_t)160 * 1024,
+                "frame too large for the GPU preprocess kernel (its source rows of one output row must fit the 160 KiB LDS)");
+        if ((int)rs_tabs.size() >= RS_CACHE) {
+            HIP_CHECK(hipStreamSynchronize(st));       // no launch may still be reading the evicted tables
+            size_t v = 0;
+            for (size_t k = 1; k < rs_tabs.size(); ++k) if (rs_tabs[k].stamp < rs_tabs[v].stamp) v = k;
+            for (void* p : rs_tabs[v].bufs) (void)hipFree(p);
+            rs_tabs.erase(rs_tabs.begin() + v);
+        }
+        ResampleTabs t; t.H = Hh; t.W = Ww; t.stamp = ++rs_clock;
         auto up = [&](const std::vector<int>& v) {
-            int* d = dalloc<int>(v.size());
+            int* d = nullptr;
+            HIP_CHECK(hipMalloc((void**)&d, v.size() * sizeof(int) + 256));
+            t.bufs.push_back(d);
             HIP_CHECK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
             return d;
         };
-        ResampleTabs t; t.H = Hh; t.W = Ww;
         t.dev.hmin = up(ah.xmin); t.dev.hcnt = up(ah.cnt); t.dev.hk = up(ah.k); t.dev.ks_h = ah.ksize;
         t.dev.vmin = up(av.xmin); t.dev.vcnt = up(av.cnt); t.dev.vk = up(av.k); t.dev.ks_v = av.ksize;
         HIP_CHECK(hipStreamSynchronize(st));          // the host vectors go out of scope
@@ -636,10 +669,7 @@ public:
             for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreate(&h2d_ev[i]));
             for (auto& pr : pp_ring) { HIP_CHECK(hipEventCreate(&pr.a)); HIP_CHECK(hipEventCreate(&pr.b)); }
         }
-        const ResampleDev& tabs = resample_tabs(Hh, Ww);
-        REQUIRE(tabs.ks_v <= 40, "frame too large for the GPU preprocess kernel (more than 40 source rows per output row)");
-        REQUIRE(preprocess_lds_bytes(Ww, Sx, tabs.ks_v, tabs.ks_h) <= (size_t)160 * 1024,
-                "frame too large for the GPU preprocess kernel (its source rows of one output row must fit the 160 KiB LDS)");
+        const ResampleDev tabs = resample_tabs(Hh, Ww);       // (by value: a later geometry may evict the cache entry)
         if (d_rgb_cap < bytes + 64) {
             HIP_CHECK(hipStreamSynchronize(st));
             if (d_rgb) HIP_CHECK(hipFree(d_rgb));
@@ -688,33 +718,37 @@ public:
         Env& e = env_at(env);
         if (src_pending) { HIP_CHECK(hipEventSynchronize(src_ev)); src_pending = false; }
         REQUIRE(frame_base >= 0 && n_memory >= 0 && frame_base + n_memory <= n_feat_frames, "n_memory exceeds encoded frames");
-        int rows = 0, img = frame_base + n_memory, mem_used = 0;
+        // rows of this turn, then the reference's per-turn truncation (new_input_embeds[:tokenizer_model_max_length], stream_video_vln.py:241-244),
+        // then the capacity check of the accumulated sequence (max_positions is this engine's buffer size; the reference has no such cap)
+        int img = frame_base + n_memory, mem_used = 0;
         const int cap = c.max_positions - e.n_embeds;
-        for (int k = 0; k < n; ++k) {
+        const size_t lim = turn_row_limit > 0 ? (size_t)turn_row_limit : (size_t)1 << 30;
+        std::vector<int> src;
+        for (int k = 0; k < n && src.size() < lim; ++k) {
             const int64_t t = ids[k];
             if (t == IMAGE_TOKEN) {
                 REQUIRE(img < n_feat_frames, "more <image> tokens than encoded frames");
-                REQUIRE(rows + otok <= cap, "inputs_embeds exceeds max_positions");
-                for (int j = 0; j < otok; ++j) h_src[rows++] = -(1 + img * otok + j);
+                for (int j = 0; j < otok; ++j) src.push_back(-(1 + img * otok + j));
                 ++img;
             } else if (t == MEMORY_TOKEN) {
                 REQUIRE(n_memory > 0 && mem_used == 0, "<memory> token without (or with repeated) memory frames");
                 const int nm = n_memory * otok;
                 if (prune_keep > 0 && prune_keep < nm) {          // opt-in: keep the prune_keep least-average memory tokens, in order
-                    REQUIRE(rows + prune_keep <= cap, "inputs_embeds exceeds max_positions");
                     run_memory_prune(feats + (size_t)frame_base * otok * H, nm, prune_keep);
-                    for (int j = 0; j < prune_keep; ++j) h_src[rows++] = -(1 + frame_base * otok + h_sel[j]);
+                    for (int j = 0; j < prune_keep; ++j) src.push_back(-(1 + frame_base * otok + h_sel[j]));
                 } else {
-                    REQUIRE(rows + nm <= cap, "inputs_embeds exceeds max_positions");
-                    for (int j = 0; j < nm; ++j) h_src[rows++] = -(1 + frame_base * otok + j);
+                    for (int j = 0; j < nm; ++j) src.push_back(-(1 + frame_base * otok + j));
                 }
                 mem_used = 1;
             } else {
                 REQUIRE(t >= 0 && t < V, "token id out of range");
-                REQUIRE(rows + 1 <= cap, "inputs_embeds exceeds max_positions");
-                h_src[rows++] = (int)t;
+                src.push_back((int)t);
             }
         }
+        if (src.size() > lim) src.resize(lim);
+        REQUIRE((int)src.size() <= cap, "inputs_embeds exceeds max_positions");
+        const int rows = (int)src.size();
+        std::memcpy(h_src, src.data(), (size_t)rows * sizeof(int));
         HIP_CHECK(hipMemcpyAsync(d_src, h_src, rows * sizeof(int), hipMemcpyHostToDevice, st));
         launch_gather_rows<T>(st, d_src, embed, feats, e.embeds + (size_t)e.n_embeds * H, rows, H);
         if (!src_ev) HIP_CHECK(hipEventCreateWithFlags(&src_ev, hipEventDisableTiming));
@@ -828,8 +862,10 @@ public:
         }
         GemvArgs a = with8(gemv_args(lm_head, H, tap, nullptr, nullptr, nullptr, nullptr, V, H, EPI_ARGMAX), lm_head8);
         a.skip = skip;
+        const bool pen = gen && rep_penalty != 1.0f;
+        if (pen) { a.pen_flags = pen_flags; a.pen = rep_penalty; }
         launch_gemv<T>(st, a);
-        if (gen) launch_argmax_step(st, part_val, part_idx, gemv_grid(V), d_token, d_top2, d_ctl, d_eos, d_out_ids);
+        if (gen) launch_argmax_step(st, part_val, part_idx, gemv_grid(V), d_token, d_top2, d_ctl, d_eos, d_out_ids, pen ? pen_flags : nullptr);
         else launch_argmax_final(st, part_val, part_idx, gemv_grid(V), d_token, d_top2);
     }
     // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_ctl,
@@ -873,8 +909,8 @@ public:
         return ex;
     }
     void drop_graphs() {
-        for (auto& g : graph_exec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-        graph_env = -1;
+        for (auto& gs : graphs)
+            for (auto& g : gs.ex) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     }
     // HIP events bracket the layer-0 gate/up GEMV (launched directly between two captured halves) while probing;
     // that launch is the same kernel, grid and bytes as the other layers' gate/up GEMVs inside the graph.
@@ -886,19 +922,15 @@ public:
         // plain timed launch; the other steps replay the whole-step graph)
         const bool probing = probe_on && tap_row == 1 && probe_used + 2 <= probe_ev.size();
         if (use_graph) {
-            if (graph_env != env) {
-                drop_graphs();
-                graph_exec[0] = capture(e, 0, n_ops);
-                graph_exec[1] = capture(e, 0, PROBE_OP);
-                graph_exec[2] = capture(e, PROBE_OP + 1, n_ops);
-                graph_env = env;
-            }
+            GraphSet& gs = graphs[env];
             if (!probing) {
-                HIP_CHECK(hipGraphLaunch(graph_exec[0], st));
+                if (!gs.ex[0]) gs.ex[0] = capture(e, 0, n_ops);
+                HIP_CHECK(hipGraphLaunch(gs.ex[0], st));
             } else {
-                HIP_CHECK(hipGraphLaunch(graph_exec[1], st));
+                if (!gs.ex[1]) { gs.ex[1] = capture(e, 0, PROBE_OP); gs.ex[2] = capture(e, PROBE_OP + 1, n_ops); }
+                HIP_CHECK(hipGraphLaunch(gs.ex[1], st));
                 probe_launch(e);
-                HIP_CHECK(hipGraphLaunch(graph_exec[2], st));
+                HIP_CHECK(hipGraphLaunch(gs.ex[2], st));
             }
         } else {
             if (!probing) {
@@ -919,16 +951,19 @@ public:
         a.y = y; a.ldy = ldy; a.N = N; a.K = K; a.epi = epi; a.B = B; a.part_val = part_val_b; a.part_idx = part_idx_b; return a;
     }
     // final norm of rows[0..B) -> lm_head once for all B envs -> d_tok_b[0..B)
-    void head_batched(const T* rows, int B) {
+    // pen: the repetition penalty is on and d_pen_rows[0..B) holds the job slot (= flag row) of every batch row
+    void head_batched(const T* rows, int B, bool pen = false) {
         launch_rmsnorm<T>(st, rows, final_norm, xn, B, H, c.rms_eps);
-        launch_gemv_batched<T>(st, gemvb_args(lm_head, H, xn, H, nullptr, nullptr, nullptr, 0, nullptr, 0, V, H, EPI_ARGMAX, B));
+        GemvBatchArgs hb = gemvb_args(lm_head, H, xn, H, nullptr, nullptr, nullptr, 0, nullptr, 0, V, H, EPI_ARGMAX, B);
+        if (pen) { hb.pen_flags = pen_flags_b; hb.pen_rows = d_pen_rows; hb.pen = rep_penalty; }
+        launch_gemv_batched<T>(st, hb);
         launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(V, EPI_ARGMAX, B), B, d_tok_b);
     }
     // One decode step for B envs (B in {1,2,4,8}; d_slots / d_tok_b already set): every weight matrix is streamed once.
     // B >= 4: the projections run as 32-row MFMA products (gemm.hip CfgSkinny: the weight stream goes through LDS-DMA, the B rows
     // ride along; the batched GEMV is dot-product-issue bound from B = 4 up) and the split-K reduce of o_proj / down_proj also emits
     // the following RMSNorm.  B <= 2: the batched GEMV (HBM-bound there).
-    void decode_ops_batched(int B) {
+    void decode_ops_batched(int B, bool pen = false) {
         const int qd = nq * 128;
         const bool mfma = B >= batched_mfma_min;
         launch_gather_rows<T>(st, d_tok_b, embed, feats, x, B, H);
@@ -957,7 +992,7 @@ public:
                 launch_gemv_batched<T>(st, gemvb_args(L.down_w, I, hbuf, I, nullptr, nullptr, x, H, x, H, H, I, EPI_NONE, B));
             }
         }
-        head_batched(x, B);
+        head_batched(x, B, pen);
     }
     bool taps_on = true;
     void tap_copy(const T* row, int token_idx, int slot) {       // parity tap: hid_tap[min(token,7)][slot]
@@ -977,6 +1012,51 @@ public:
         std::vector<int64_t> out, eos;
     };
     Job jobs[MAXB];
+    // forget a job: its slot becomes free, its repetition-penalty flags are cleared (the stream is idle between scheduler calls)
+    void drop_job(int k) {
+        Job& j = jobs[k];
+        if (!j.used) return;
+        if (pen_flags_b && !j.out.empty()) {
+            const int n = (int)j.out.size() < c.max_positions ? (int)j.out.size() : c.max_positions;
+            for (int q = 0; q < n; ++q) h_pen_ids[q] = (int)j.out[q];
+            (void)hipMemcpyAsync(d_pen_ids, h_pen_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st);
+            launch_set_flags(st, pen_flags_b + (size_t)k * V, d_pen_ids, nullptr, n, 0);
+            (void)hipStreamSynchronize(st);          // h_pen_ids is reused by the next drop
+        }
+        j = Job();
+    }
+    void cancel_jobs_of(int env) {
+        for (int k = 0; k < MAXB; ++k) if (jobs[k].used && jobs[k].env == env) drop_job(k);
+    }
+    // svln_batch_cancel: slot >= 0 drops that turn, slot < 0 every turn in flight.  The envs keep whatever rows / KV the dropped turns
+    // had already written (a cancelled prefill leaves kv_len behind n_embeds: reset the env, or submit it again to finish the prefill).
+    void batch_cancel(int slot) override {
+        REQUIRE(slot < MAXB, "no such scheduler slot");
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (slot >= 0) drop_job(slot);
+        else for (int k = 0; k < MAXB; ++k) drop_job(k);
+    }
+    void ensure_pen_buffers() {
+        if (pen_flags) return;
+        pen_flags = dalloc<uint8_t>((size_t)V, true);
+        pen_flags_b = dalloc<uint8_t>((size_t)MAXB * V, true);
+        d_pen_rows = dalloc<int>(MAXB, true);
+        d_pen_ids = dalloc<int>((size_t)c.max_positions + 8);
+        HIP_CHECK(hipHostMalloc((void**)&h_pen_rows, MAXB * sizeof(int)));
+        HIP_CHECK(hipHostMalloc((void**)&h_pen_ids, ((size_t)c.max_positions + 8) * sizeof(int)));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // generation_config.repetition_penalty of a checkpoint (HF RepetitionPenaltyLogitsProcessor over the tokens generated in the turn;
+    // transformers 4.45.1 applies it under greedy decoding too).  1 = off (the default: no kernel sees a flag pointer).
+    void set_repetition_penalty(float penalty) override {
+        REQUIRE(penalty > 0.0f, "repetition_penalty must be > 0");
+        for (int k = 0; k < MAXB; ++k) REQUIRE(!jobs[k].used, "repetition_penalty cannot change while turns are in flight");
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (penalty != 1.0f) ensure_pen_buffers();
+        if (penalty != rep_penalty) drop_graphs();           // the captured lm_head launch holds the flag pointer and the factor
+        rep_penalty = penalty;
+    }
+    void set_turn_row_limit(int rows) override { REQUIRE(rows >= 0, "row limit must be >= 0 (0 = none)"); turn_row_limit = rows; }
     int batch_submit(int env, int max_new, const int64_t* eos, int n_eos) override {
         Env& e = env_at(env);
         REQUIRE(weights_missing() == 0, g_err);
@@ -998,20 +1078,46 @@ public:
     // one iteration; returns the number of jobs still running afterwards, finished_slots = jobs that completed in this iteration
     int batch_step(int32_t* finished_slots, int32_t* n_finished) override {
         *n_finished = 0;
+        // a turn whose env has nothing left to prefill (its rows were reset or already consumed) is dropped alone, with an error that
+        // names it; the other turns stay valid for the next call
+        for (int k = 0; k < MAXB; ++k) {
+            Job& j = jobs[k];
+            if (!j.used || j.finished || !j.prefill) continue;
+            const Env& e = envs[j.env];
+            if (e.n_embeds - e.kv_len < 1) {
+                const int env = j.env;
+                drop_job(k);
+                REQUIRE(false, "batch_step: env " + std::to_string(env) + " has no rows to prefill (reset after submit?); its turn was dropped");
+            }
+        }
+        try {
+            return batch_step_run(finished_slots, n_finished);
+        } catch (...) {
+            // the iteration failed part-way (page pool exhausted, non-finite logits, a HIP error): which jobs advanced is unknown, so every
+            // turn in flight is dropped and the scheduler is idle again; the envs keep their rows (reset them or submit again)
+            (void)hipStreamSynchronize(st);
+            for (int k = 0; k < MAXB; ++k) drop_job(k);
+            *n_finished = 0;
+            throw;
+        }
+    }
+    int batch_step_run(int32_t* finished_slots, int32_t* n_finished) {
         std::vector<int> dec, pre;                      // job slots decoding / prefilling in this iteration
         for (int k = 0; k < MAXB; ++k)
             if (jobs[k].used && !jobs[k].finished) (jobs[k].prefill ? pre : dec).push_back(k);
         if (dec.empty() && pre.empty()) return 0;
         const int nd = (int)dec.size();
-        // prefill jobs that fit the row workspaces next to the decode rows (the rest wait for the next iteration)
+        const bool pen = rep_penalty != 1.0f;
+        // prefill jobs that fit the row workspaces next to the decode rows (the rest wait for the next iteration; a turn of up to
+        // max_positions rows runs as soon as no decode row shares the pass)
         std::vector<Seg> segs;
         std::vector<int> pre_now;
         int M = nd;
         for (int k : pre) {
             Env& e = envs[jobs[k].env];
             const int Tn = e.n_embeds - e.kv_len;
-            REQUIRE(Tn <= c.max_positions - MAXB, "prefill longer than the row workspace");
-            if (!segs.empty() && M + Tn > c.max_positions) continue;
+            REQUIRE(Tn >= 1 && Tn <= c.max_positions, "prefill length out of range");
+            if (M + Tn > c.max_positions) continue;
             ensure_pages(e, e.n_embeds);
             segs.push_back(Seg{&e, e.kv_len, Tn, M});
             pre_now.push_back(k);
@@ -1029,11 +1135,13 @@ public:
                 if (k < nd) ensure_pages(e, e.kv_len + 1);
                 h_slots[k].page_table = e.d_pages; h_slots[k].pos = e.kv_len; h_slots[k].pad = 0;
                 h_tok_b[k] = jobs[dec[kk]].last_tok;
+                if (pen) h_pen_rows[k] = dec[kk];
             }
             HIP_CHECK(hipMemcpyAsync(d_slots, h_slots, B * sizeof(DecodeSlot), hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(d_tok_b, h_tok_b, B * sizeof(int), hipMemcpyHostToDevice, st));
             if (segs.empty()) {
-                decode_ops_batched(B);                   // gather + 28 layers + head for B decode rows -> d_tok_b, xn = final-norm rows
+                if (pen) HIP_CHECK(hipMemcpyAsync(d_pen_rows, h_pen_rows, B * sizeof(int), hipMemcpyHostToDevice, st));
+                decode_ops_batched(B, pen);              // gather + 28 layers + head for B decode rows -> d_tok_b, xn = final-norm rows
             } else {
                 launch_gather_rows<T>(st, d_tok_b, embed, feats, x, nd, H);
             }
@@ -1053,7 +1161,11 @@ public:
             int Bp = 1; while (Bp < nj) Bp <<= 1;
             for (int k = nj; k < Bp; ++k)
                 HIP_CHECK(hipMemcpyAsync(last_rows + (size_t)k * H, last_rows, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
-            head_batched(last_rows, Bp);
+            if (pen) {
+                for (int k = 0; k < Bp; ++k) h_pen_rows[k] = order[k < nj ? k : 0];
+                HIP_CHECK(hipMemcpyAsync(d_pen_rows, h_pen_rows, Bp * sizeof(int), hipMemcpyHostToDevice, st));
+            }
+            head_batched(last_rows, Bp, pen);
         }
         const int nj = (int)order.size();
         for (int q = 0; q < nj; ++q) tap_copy(xn + (size_t)q * H, jobs[order[q]].count, order[q]);
@@ -1078,12 +1190,18 @@ public:
             j.last_tok = tok;
             bool stop = j.count >= j.max_new;
             for (int64_t id : j.eos) stop |= id == tok;
+            if (pen && !stop) {                                               // the token counts as generated for this job's next arg-max
+                h_pen_ids[q] = tok;
+                HIP_CHECK(hipMemcpyAsync(d_pen_ids + q, h_pen_ids + q, sizeof(int), hipMemcpyHostToDevice, st));
+                launch_set_flags(st, pen_flags_b + (size_t)order[q] * V, d_pen_ids + q, nullptr, 1, 1);
+            }
             if (stop) {
                 j.finished = true;
                 n_generated_b[order[q]] = j.count;
                 finished_slots[(*n_finished)++] = order[q];
             }
         }
+        if (pen) HIP_CHECK(hipStreamSynchronize(st));                         // h_pen_ids is rewritten by the next iteration
         int running = 0;
         for (int k = 0; k < MAXB; ++k) running += jobs[k].used && !jobs[k].finished;
         return running;
@@ -1094,7 +1212,7 @@ public:
         const int n = (int)j.out.size();
         for (int k = 0; k < n && k < cap; ++k) out[k] = j.out[k];
         *n_out = n; *env = j.env;
-        j.used = false;
+        drop_job(slot);
     }
     // svln_generate on each listed env, executed together: submit all, iterate until all are done (all envs prefill in the first
     // iteration and decode in lockstep afterwards: the special case of the scheduler in which every turn falls due at once)
@@ -1111,7 +1229,7 @@ public:
             int32_t fin[MAXB], nf = 0;
             while (batch_step(fin, &nf) > 0) {}
         } catch (...) {
-            for (int k = 0; k < MAXB; ++k) jobs[k].used = false;
+            for (int k = 0; k < MAXB; ++k) drop_job(k);
             throw;
         }
         for (int s = 0; s < n_envs; ++s) {
@@ -1161,6 +1279,8 @@ public:
         // the first decode step feeds token 0 at position L: pos / kv_len advance when the arg-max step appends without stopping
         h_ctl->pos = L - 1; h_ctl->kv_len = L; h_ctl->done = 0; h_ctl->count = 0; h_ctl->max_new = limit; h_ctl->n_eos = n_eos;
         h_ctl->pad0 = h_ctl->pad1 = 0;
+        if (rep_penalty != 1.0f)      // tokens of the previous generate (still listed in d_out_ids[0 .. d_ctl.count)) no longer count
+            launch_set_flags(st, pen_flags, d_out_ids, &d_ctl->count, 0, 0);
         HIP_CHECK(hipMemcpyAsync(d_ctl, h_ctl, sizeof(GenCtl), hipMemcpyHostToDevice, st));
         HIP_CHECK(hipEventRecord(ph_ev[2], st));
         prefill(e, P, Tn);
@@ -1511,6 +1631,9 @@ int svln_batch_step(svln_engine* h, int32_t* running, int32_t* finished_slots, i
 int svln_batch_result(svln_engine* h, int slot, int32_t* env, int64_t* out_ids, int out_cap, int32_t* n_out) {
     API_BEGIN_H h->impl->batch_result(slot, env, out_ids, out_cap, n_out); API_END
 }
+int svln_batch_cancel(svln_engine* h, int slot) { API_BEGIN_H h->impl->batch_cancel(slot); API_END }
+int svln_set_turn_row_limit(svln_engine* h, int rows) { API_BEGIN_H h->impl->set_turn_row_limit(rows); API_END }
+int svln_set_repetition_penalty(svln_engine* h, float penalty) { API_BEGIN_H h->impl->set_repetition_penalty(penalty); API_END }
 int svln_get_hidden_batch(svln_engine* h, int slot, float* out, int max_rows, int32_t* n_rows) { API_BEGIN_H h->impl->get_hidden_batch(slot, out, max_rows, n_rows); API_END }
 int svln_generate(svln_engine* h, int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out) {
     API_BEGIN_H h->impl->generate(env, max_new, eos, n_eos, out, cap, n_out, false); API_END

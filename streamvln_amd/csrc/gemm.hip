@@ -55,7 +55,6 @@ using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for mor
 using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
                                                              // products with few 128-wide column tiles and a short K (force_cfg 64 only, see launch_epi)
 using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockstep decode of several envs): 2 waves, 20 KB stages, glds kernel only
-using CfgBig4 = TileCfg<256, 256, 2, 2, 128, false, 2>;      // 4 waves, wave tile 128x128 (4x4 accumulators in AGPRs): half the LDS fragment reads per MFMA       // 8 waves, wave tile 128x64 (4x2 accumulators), glds kernel only
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
 

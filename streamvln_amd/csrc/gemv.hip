@@ -306,9 +306,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_batched_kernel(GemvBatchArg
             }
         } else if (EPI == EPI_ARGMAX) {
             if (tid < B) {
+                const uint8_t* fl = p.pen_flags ? p.pen_flags + (size_t)p.pen_rows[tid] * p.N : nullptr;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float v = total(r * B + tid);
+                    float v = total(r * B + tid);
+                    if (fl && n0 + r < p.N && fl[n0 + r]) v = v < 0.0f ? v * p.pen : v / p.pen;
                     if (n0 + r < p.N && v > best) { best = v; best_i = n0 + r; }      // units ascend per workgroup: first max wins
                 }
             }
@@ -412,6 +414,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] *= xscale;
         if (EPI == EPI_ARGMAX) {
+            if (p.pen_flags) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (n0 + r < p.N && p.pen_flags[n0 + r]) acc[r] = acc[r] < 0.0f ? acc[r] * p.pen : acc[r] / p.pen;
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (n0 + r < p.N && acc[r] > best) { best = acc[r]; best_i = n0 + r; }     // rows ascend: first max wins
@@ -585,6 +592,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv8_kernel(GemvArgs p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] *= p.scale[min(n0 + r, p.N - 1)] * xscale;
         if (EPI == EPI_ARGMAX) {
+            if (p.pen_flags) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (n0 + r < p.N && p.pen_flags[n0 + r]) acc[r] = acc[r] < 0.0f ? acc[r] * p.pen : acc[r] / p.pen;
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (n0 + r < p.N && acc[r] > best) { best = acc[r]; best_i = n0 + r; }
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* w, int 
 // final arg-max over per-workgroup partials: greatest value, lowest index on ties (torch.argmax on CPU)
 // With `ctl` it is also one step of the greedy loop (GenerationMixin._sample: append, stop on EOS / max_new_tokens): see GenCtl.
 __global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, const int* pi, int n, int* out_token, float* out_top, GenCtl* ctl,
-                                                           const int* eos, int* out_ids) {
+                                                           const int* eos, int* out_ids, uint8_t* pen_flags) {
     __shared__ float sv[256];
     if (ctl && ctl->done) return;
     __shared__ int si[256];
@@ -746,6 +758,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* pv, cons
         if (threadIdx.x == 0) {
             const int c = ctl->count;
             out_ids[c] = tok;
+            if (pen_flags && tok >= 0) pen_flags[tok] = 1;
             ctl->count = c + 1;
             if (hit || tok < 0 || c + 1 >= ctl->max_new) ctl->done = 1;      // EOS is appended, never fed
             else { ctl->pos += 1; ctl->kv_len += 1; }
@@ -849,17 +862,16 @@ void launch_argmax_final_batched(hipStream_t s, const float* pv, const int* pi, 
 template void launch_gemv_timed<bf16>(hipStream_t, const GemvArgs&, hipEvent_t, hipEvent_t);
 template void launch_gemv_timed<float>(hipStream_t, const GemvArgs&, hipEvent_t, hipEvent_t);
 template <typename T, int EPI> static void gemv_attr() {
-    (void)hipFuncSetAttribute((const void*)gemv_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    set_max_lds((const void*)gemv_kernel<T, EPI>, 160 * 1024 - 256);
 }
-template <typename T> static void gemv_ksplit_attr() {}
 void launch_quant_fp8_rows(hipStream_t s, const void* w_bf16, int ld, void* w8, float* scale, int64_t rows, int cols) {
     hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, (const bf16*)w_bf16, ld, (uint8_t*)w8, scale, cols);
 }
 void gemv_init_attrs() {
-    (void)hipFuncSetAttribute((const void*)gemv8_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute((const void*)gemv8_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute((const void*)gemv8_kernel<EPI_ARGMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    gemv_ksplit_attr<bf16>(); gemv_ksplit_attr<float>();
+    // (every kernel that may ask for more than 64 KiB of dynamic LDS goes through set_max_lds: a refusal is reported at engine creation)
+    set_max_lds((const void*)gemv8_kernel<EPI_NONE>, 160 * 1024 - 256);
+    set_max_lds((const void*)gemv8_kernel<EPI_SWIGLU>, 160 * 1024 - 256);
+    set_max_lds((const void*)gemv8_kernel<EPI_ARGMAX>, 160 * 1024 - 256);
     gemv_attr<bf16, EPI_NONE>(); gemv_attr<bf16, EPI_SWIGLU>(); gemv_attr<bf16, EPI_ARGMAX>();
     gemv_attr<float, EPI_NONE>(); gemv_attr<float, EPI_SWIGLU>(); gemv_attr<float, EPI_ARGMAX>();
 }
@@ -867,11 +879,22 @@ template void launch_gemv<bf16>(hipStream_t, const GemvArgs&);
 template void launch_gemv<float>(hipStream_t, const GemvArgs&);
 
 void launch_argmax_final(hipStream_t s, const float* pv, const int* pi, int n, int* out_token, float* out_top) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top, (GenCtl*)nullptr, (const int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top, (GenCtl*)nullptr, (const int*)nullptr, (int*)nullptr,
+                       (uint8_t*)nullptr);
 }
 void launch_argmax_step(hipStream_t s, const float* pv, const int* pi, int n, int* out_token, float* out_top, GenCtl* ctl, const int* eos,
-                        int* out_ids) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top, ctl, eos, out_ids);
+                        int* out_ids, uint8_t* pen_flags) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pv, pi, n, out_token, out_top, ctl, eos, out_ids, pen_flags);
+}
+namespace {
+__global__ __launch_bounds__(256) void set_flags_kernel(uint8_t* flags, const int* ids, const int* count, int n_host, int value) {
+    const int n = count ? *count : n_host;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256)
+        if (ids[k] >= 0) flags[ids[k]] = (uint8_t)value;
+}
+}  // namespace
+void launch_set_flags(hipStream_t s, uint8_t* flags, const int* ids, const int* count, int n_host, int value) {
+    hipLaunchKernelGGL(set_flags_kernel, dim3(count ? 16 : (n_host + 255) / 256 > 0 ? (n_host + 255) / 256 : 1), dim3(256), 0, s, flags, ids, count, n_host, value);
 }
 
 }  // namespace svln

@@ -66,6 +66,10 @@ struct GemvArgs {
     // W[n][k] ~= scale[n] * e4m3(w8[n][k]); when set, W is ignored
     const void* w8; const float* scale;
     const int* skip;              // optional device flag: the launch is a no-op when *skip != 0 (generation finished: run-ahead decode steps)
+    // EPI_ARGMAX only, optional: HF RepetitionPenaltyLogitsProcessor on the fp32 logits before the arg-max (a checkpoint's
+    // generation_config.json `repetition_penalty`): pen_flags[n] != 0 marks token n as already generated in this turn;
+    // its logit becomes v < 0 ? v * pen : v / pen.  null = no penalty.
+    const uint8_t* pen_flags = nullptr; float pen = 1.0f;
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 // per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 16 == 0): scale[r] = max|W[r]| / 448
@@ -84,6 +88,8 @@ struct GemvBatchArgs {
     void* y; int ldy;
     int N, K, epi, B;
     float* part_val; int* part_idx;
+    // EPI_ARGMAX only, optional repetition penalty (see GemvArgs): row b of the batch uses the flag row pen_rows[b] of pen_flags [.][N]
+    const uint8_t* pen_flags = nullptr; const int* pen_rows = nullptr; float pen = 1.0f;
 };
 template <typename T> void launch_gemv_batched(hipStream_t s, const GemvBatchArgs& a);
 int gemv_batched_grid(int N, int epi, int B);
@@ -101,8 +107,11 @@ struct GenCtl {
 };
 // launch_argmax_final + the bookkeeping above: out_ids[count++] = token; done |= token in eos[0 .. n_eos) || count == max_new || token < 0;
 // otherwise pos / kv_len advance by one.  No-op when ctl->done is already set.
+// pen_flags (optional): the emitted token's byte is set (repetition penalty of the following steps)
 void launch_argmax_step(hipStream_t s, const float* part_val, const int* part_idx, int n, int* out_token, float* out_top, GenCtl* ctl,
-                        const int* eos, int* out_ids);
+                        const int* eos, int* out_ids, uint8_t* pen_flags = nullptr);
+// flags[ids[k]] = value for k < *count (count: device scalar) or k < n_host when count is null; ids < 0 are skipped
+void launch_set_flags(hipStream_t s, uint8_t* flags, const int* ids, const int* count, int n_host, int value);
 
 // Flash-style attention over paged K / V^T tiles (64 keys per page).
 //   pools:  K  [page][n_kv_total][64][HDP]        HDP = head dim padded to an even chunk count

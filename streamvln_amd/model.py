@@ -176,8 +176,13 @@ class StreamVLNForCausalLM:
         self._tower = _VisionTower(config, engine=(lib, h), device_index=device)
         # `.model` = StreamVLNModel in the reference; callers set `.model.num_history` (streamvln_eval.py:531)
         self.model = SimpleNamespace(num_history=None, get_vision_tower=lambda: self._tower)
-        self.config = SimpleNamespace(mm_spatial_pool_mode="bilinear", hidden_size=config.hidden, vocab_size=config.vocab)
-        self.generation_config = SimpleNamespace(eos_token_id=[151645, 151643])   # Qwen2-7B-Instruct <|im_end|>, <|endoftext|>
+        # tokenizer_model_max_length: read at every call like the reference does (stream_video_vln.py:241-244); None = no truncation
+        self.config = SimpleNamespace(mm_spatial_pool_mode="bilinear", hidden_size=config.hidden, vocab_size=config.vocab,
+                                      tokenizer_model_max_length=None)
+        # Qwen2-7B-Instruct <|im_end|>, <|endoftext|>; repetition_penalty as transformers' GenerationConfig defaults it
+        self.generation_config = SimpleNamespace(eos_token_id=[151645, 151643], repetition_penalty=1.0)
+        self._row_limit, self._rep_penalty = 0, 1.0           # what the engine currently holds
+        self._tickets: Dict[int, tuple] = {}
         self.reset(max_envs)
 
     # ---- construction -------------------------------------------------------------------------
@@ -212,11 +217,15 @@ class StreamVLNForCausalLM:
         else:
             cfg = TRUE
         m = cls(cfg, dtype=torch_dtype, device=device, **kw)
+        hf = config if config is not None and not isinstance(config, StreamVLNConfig) else None
+        if hf is None and os.path.exists(os.path.join(str(path), "config.json")):
+            hf = json.load(open(os.path.join(str(path), "config.json")))
+        if hf is not None:
+            tml = hf.get("tokenizer_model_max_length") if isinstance(hf, dict) else getattr(hf, "tokenizer_model_max_length", None)
+            m.config.tokenizer_model_max_length = None if tml is None else int(tml)
         gen = os.path.join(str(path), "generation_config.json")
-        if os.path.exists(gen):                                   # stop ids of the checkpoint
-            eos = json.load(open(gen)).get("eos_token_id")
-            if eos is not None:
-                m.generation_config.eos_token_id = list(eos) if isinstance(eos, (list, tuple)) else [int(eos)]
+        if os.path.exists(gen):                                   # the checkpoint's generation defaults
+            m.apply_generation_config(json.load(open(gen)))
         for f in files:
             with safe_open(f, framework="pt") as sf:
                 for name in sf.keys():
@@ -224,6 +233,57 @@ class StreamVLNForCausalLM:
                         m.set_tensor(name, sf.get_tensor(name))
         m.check_weights()
         return m
+
+    #: generation_config.json keys that would change what `generate(do_sample=False, num_beams=1, max_new_tokens=...)` returns in
+    #: transformers 4.45.1 and that the engine does not implement -> an error at load time, never a silently different answer.
+    #: (value = the neutral setting.)  Sampling knobs (temperature / top_k / top_p / typical_p ...) are inert under the harness's
+    #: explicit do_sample=False and are ignored, as HF itself does (with a warning).
+    _UNSUPPORTED_GENERATION_KEYS = {
+        "no_repeat_ngram_size": 0, "encoder_repetition_penalty": 1.0, "encoder_no_repeat_ngram_size": 0, "bad_words_ids": None,
+        "min_length": 0, "min_new_tokens": None, "forced_bos_token_id": None, "forced_eos_token_id": None, "suppress_tokens": None,
+        "begin_suppress_tokens": None, "sequence_bias": None, "penalty_alpha": None, "guidance_scale": None, "num_beam_groups": 1,
+        "diversity_penalty": 0.0, "length_penalty": 1.0, "exponential_decay_length_penalty": None, "renormalize_logits": False,
+        "remove_invalid_values": False, "forced_decoder_ids": None, "constraints": None, "force_words_ids": None,
+        "prompt_lookup_num_tokens": None, "assistant_model": None, "dola_layers": None, "watermarking_config": None,
+    }
+
+    def apply_generation_config(self, gen: dict):
+        """A checkpoint's generation_config.json -> the stop ids and the repetition penalty of the greedy loop; any other key that
+        changes greedy decoding raises."""
+        eos = gen.get("eos_token_id")
+        if eos is not None:
+            self.generation_config.eos_token_id = list(eos) if isinstance(eos, (list, tuple)) else [int(eos)]
+        rp = gen.get("repetition_penalty")
+        if rp is not None:
+            if not float(rp) > 0:
+                raise ValueError(f"generation_config.repetition_penalty must be > 0, got {rp}")
+            self.generation_config.repetition_penalty = float(rp)
+        bad = []
+        for k, neutral in self._UNSUPPORTED_GENERATION_KEYS.items():
+            v = gen.get(k, neutral)
+            if v is None or v == neutral or (isinstance(v, (list, dict)) and not v):
+                continue
+            if k == "length_penalty" and int(gen.get("num_beams", 1)) == 1:
+                continue                                          # beam-search only
+            bad.append(f"{k}={v!r}")
+        if bad:
+            raise NotImplementedError("generation_config.json changes greedy decoding in ways the HIP path does not implement: "
+                                      + ", ".join(bad))
+
+    def _sync_call_config(self):
+        """config.tokenizer_model_max_length and generation_config.repetition_penalty are plain attributes the caller may change
+        between calls (the reference reads them at call time): push them to the engine when they differ from what it holds."""
+        tml = getattr(self.config, "tokenizer_model_max_length", None)
+        lim = 0 if tml is None else int(tml)
+        if lim < 0:
+            raise ValueError("tokenizer_model_max_length must be >= 0")
+        if lim != self._row_limit:
+            _check(self._lib.svln_set_turn_row_limit(self._h, lim))
+            self._row_limit = lim
+        rp = float(getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0)
+        if rp != self._rep_penalty:
+            _check(self._lib.svln_set_repetition_penalty(self._h, rp))
+            self._rep_penalty = rp
 
     def tensor_names(self):
         return {s.name for s in tensor_specs(self.cfg)}
@@ -304,6 +364,8 @@ class StreamVLNForCausalLM:
         self.curr_t = [0] * env_num
         self._epoch = [0] * env_num
         self._slots: Dict[int, int] = {}
+        _check(self._lib.svln_batch_cancel(self._h, -1))           # turns still in the scheduler belong to the old state
+        self._tickets.clear()
         for i in range(self.max_envs):
             _check(self._lib.svln_reset_env(self._h, i))
 
@@ -324,7 +386,9 @@ class StreamVLNForCausalLM:
         self.curr_t[env_idx] = 0
         self._epoch[env_idx] += 1
         if env_idx in self._slots:
-            _check(self._lib.svln_reset_env(self._h, self._slots[env_idx]))
+            _check(self._lib.svln_reset_env(self._h, self._slots[env_idx]))       # (drops the env's scheduler turn, if any)
+        for slot in [k for k, v in self._tickets.items() if v[0] == env_idx]:
+            del self._tickets[slot]
 
     # ---- the call (stream_video_vln.py:353-407) -------------------------------------------------------
     def _parse_call(self, inputs, images, kwargs):
@@ -390,6 +454,7 @@ class StreamVLNForCausalLM:
     def generate(self, inputs=None, images=None, image_sizes=None, depths=None, poses=None, intrinsics=None, task_ids=None,
                  **kwargs):
         ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
+        self._sync_call_config()
         on_dev = int(pix.is_cuda)
         if on_dev:
             self._order_engine_after(pix)
@@ -427,6 +492,9 @@ class StreamVLNForCausalLM:
         max_new, eos = parsed[0][7], parsed[0][8]
         if any(p[7] != max_new or p[8] != eos for p in parsed):
             raise ValueError("max_new_tokens / eos_token_ids must be the same for every request of a batch")
+        if self._tickets:
+            raise RuntimeError("generate_batch needs an idle scheduler: collect or cancel the submitted turns first")
+        self._sync_call_config()
         # vision: encode the frames of as many requests as fit the frame buffer per call, then splice per env
         i = 0
         while i < len(parsed):
@@ -467,6 +535,14 @@ class StreamVLNForCausalLM:
         iteration, sharing its pass over the weights with whatever the other envs in flight are doing (prefill or decode).
         Returns a ticket; the result arrives from `step_batch`."""
         ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
+        # refuse BEFORE the env's state changes (frames encoded, curr_t advanced, rows spliced): a turn the scheduler cannot take must
+        # leave the env exactly as it was, so that the caller can retry it later
+        if any(v[0] == env_id for v in self._tickets.values()):
+            raise RuntimeError(f"env_id {env_id} already has a turn in flight")
+        if len(self._tickets) >= 8:
+            raise RuntimeError("at most 8 turns in flight: collect finished turns with step_batch first")
+        if not self._tickets:
+            self._sync_call_config()          # (the penalty cannot change while turns are in flight)
         on_dev = int(pix.is_cuda)
         if on_dev:
             self._order_engine_after(pix)
@@ -480,8 +556,6 @@ class StreamVLNForCausalLM:
         slot = C.c_int32()
         _check(self._lib.svln_batch_submit(self._h, self._slot(env_id), min(max_new, self.cfg.max_positions),
                                            eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size, C.byref(slot)))
-        if not hasattr(self, "_tickets"):
-            self._tickets = {}
         self._tickets[slot.value] = (env_id, inputs)
         return SimpleNamespace(env_id=env_id, slot=slot.value)
 
@@ -491,7 +565,13 @@ class StreamVLNForCausalLM:
         a list of (ticket, GenerateOutput) for the turns that ended in this iteration, `running` the number still in flight."""
         running, nf = C.c_int32(), C.c_int32()
         fin = (C.c_int32 * 8)()
-        _check(self._lib.svln_batch_step(self._h, C.byref(running), fin, C.byref(nf)))
+        try:
+            _check(self._lib.svln_batch_step(self._h, C.byref(running), fin, C.byref(nf)))
+        except Exception:
+            # the engine has dropped the failing turn(s); drop the rest too so that tickets and engine slots cannot disagree
+            self._lib.svln_batch_cancel(self._h, -1)
+            self._tickets.clear()
+            raise
         done = []
         cap = self.cfg.max_positions
         for k in range(nf.value):
@@ -501,6 +581,15 @@ class StreamVLNForCausalLM:
             env_id, inputs = self._tickets.pop(fin[k])
             done.append((SimpleNamespace(env_id=env_id, slot=fin[k]), self._result(env_id, out[: n.value], inputs)))
         return done, running.value
+
+    def cancel(self, ticket=None):
+        """Drop a submitted turn (ticket from `submit`), or every turn in flight (ticket=None)."""
+        slot = -1 if ticket is None else int(ticket.slot)
+        _check(self._lib.svln_batch_cancel(self._h, slot))
+        if ticket is None:
+            self._tickets.clear()
+        else:
+            self._tickets.pop(slot, None)
 
     def last_hidden_batch(self, slot: int) -> np.ndarray:
         buf = np.empty((8, self.cfg.hidden), dtype=np.float32)

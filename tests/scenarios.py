@@ -19,7 +19,21 @@ SCENARIOS = {
     # true dimensions, 4 ViT + 4 LLM layers, full vocabulary (152 064): first turn + one steady turn, 4 tokens each
     "true4_episode": dict(cfg=TRUE4, steps=8, num_frames=32, nfs=4, num_history=8, max_new=4, eos_mod=0,
                           lens=(181, 190, 16)),
+    # config.tokenizer_model_max_length = 150 (stream_video_vln.py:241-244): every turn's spliced rows (235 first, 211 later) are cut to 150,
+    # in the middle of the image block
+    "tiny_truncate": dict(cfg=TINY, steps=12, num_frames=12, nfs=4, num_history=2, max_new=4, eos_mod=0, lens=(40, 48, 16), tml=150),
+    # generation_config.repetition_penalty = 1.3 (transformers RepetitionPenaltyLogitsProcessor under greedy decoding): the unpenalised
+    # tiny run repeats ids inside a turn ([1507, 153, 153, 153, ...]), so the penalty changes the sequence
+    "tiny_penalty": dict(cfg=TINY, steps=16, num_frames=12, nfs=4, num_history=2, max_new=6, eos_mod=0, lens=(40, 48, 16), rep_penalty=1.3),
 }
+
+
+def apply_knobs(model, sc):
+    """the two call-time attributes of the reference's model object, set the same way on the reference, the oracle and the HIP model"""
+    if "tml" in sc:
+        model.config.tokenizer_model_max_length = sc["tml"]
+    if "rep_penalty" in sc:
+        model.generation_config.repetition_penalty = sc["rep_penalty"]
 
 
 def eos_ids(sc):

@@ -22,7 +22,8 @@ _engines = {}
 def engine(cfg, dtype):
     key = (cfg.name, dtype)
     if key not in _engines:
-        _engines[key] = StreamVLNForCausalLM(cfg, dtype=dtype, max_envs=1, max_frames=3, max_positions=2048)
+        # true width: room for the window-restart shapes (9-frame ViT batch, T = 1952 prefill)
+        _engines[key] = StreamVLNForCausalLM(cfg, dtype=dtype, max_envs=1, max_frames=9 if cfg is TRUE1 else 3, max_positions=2048)
     return _engines[key]
 
 
@@ -496,9 +497,12 @@ def _llm_attention_oracle(cfg, qkv_ctx, qkv_new, P):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg,T,P,nsplit", [(TINY, 212, 0, 1), (TINY, 37, 300, 1), (TINY, 1, 777, 8), (TINY, 3, 130, 8),
-                                            (TRUE1, 212, 800, 1), (TRUE1, 1, 1500, 8), (TRUE1, 376, 0, 1)])
+                                            (TRUE1, 212, 800, 1), (TRUE1, 1, 1500, 8), (TRUE1, 376, 0, 1),
+                                            (TRUE1, 1952, 0, 1), (TRUE1, 212, 1740, 1)])
 def test_attention_llm(dtype, cfg, T, P, nsplit):
-    """prefill (causal, bottom-right aligned over a cached context) and split-KV decode, incl. RoPE + paged KV append"""
+    """prefill (causal, bottom-right aligned over a cached context) and split-KV decode, incl. RoPE + paged KV append.
+    (TRUE1, 1952, 0): the window-restart turn -- 107 row blocks per kv head, unsplit keys, no cached context;
+    (TRUE1, 212, 1740): a steady turn late in the window (split-KV over 31 key pages)."""
     m = engine(cfg, dtype)
     ld = (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim
     ctx = q(rnd((max(P, 1), ld), 31), dtype)
@@ -512,7 +516,7 @@ def test_attention_llm(dtype, cfg, T, P, nsplit):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg,F", [(TINY, 1), (TINY, 3), (TRUE1, 2)])
+@pytest.mark.parametrize("cfg,F", [(TINY, 1), (TINY, 3), (TRUE1, 1), (TRUE1, 2), (TRUE1, 9)])      # F = 9: the window-restart batch (unsplit keys)
 def test_attention_vit(dtype, cfg, F):
     m = engine(cfg, dtype)
     S, Hv, nh, hd = cfg.v_tokens, cfg.v_hidden, cfg.v_heads, cfg.v_head_dim

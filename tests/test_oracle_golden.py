@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import streamvln_oracle as O
-from scenarios import SCENARIOS, SEED, run_scenario
+from scenarios import SCENARIOS, SEED, apply_knobs, run_scenario
 from streamvln_amd import weights as W
 from streamvln_amd.synthetic import synthetic_frame
 from util import load_golden
@@ -15,6 +15,7 @@ def _replay(name, steps=None):
     sc, g = SCENARIOS[name], load_golden(name)
     cfg = sc["cfg"]
     orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=sc["num_history"])
+    apply_knobs(orc, sc)
     log = run_scenario(orc, sc, preprocess=lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb)), steps=steps)
     for t, rec in enumerate(log):
         out = rec["out"]
@@ -27,6 +28,27 @@ def _replay(name, steps=None):
 
 def test_tiny_episode_matches_reference_fixture():
     assert _replay("tiny_episode") == 9
+
+
+def test_truncated_turns_match_reference_fixture():
+    """config.tokenizer_model_max_length = 150 through the reference's own prepare_inputs_labels_for_multimodal (stream_video_vln.py:241-244)"""
+    assert _replay("tiny_truncate") == 3
+    g = load_golden("tiny_truncate")
+    assert [int(g[f"t{t}_embeds_rows"]) for t in range(3)] == [150, 150, 150]
+
+
+def test_repetition_penalty_matches_reference_fixture_and_transformers():
+    """generation_config.repetition_penalty = 1.3: the fixture was produced with transformers' own RepetitionPenaltyLogitsProcessor inside
+    the restated greedy loop (oracle/ref_harness.py); the oracle's formula equals that class on random logits, negative values included."""
+    assert _replay("tiny_penalty") == 4
+    from transformers import RepetitionPenaltyLogitsProcessor
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(500, generator=g) * 3
+    gen = [7, 7, 13, 499, 0, 250]
+    exp = RepetitionPenaltyLogitsProcessor(penalty=1.3)(torch.tensor([gen]), logits[None].clone())[0]
+    got = O.repetition_penalty(logits, gen, 1.3)
+    assert torch.equal(got, exp) and not torch.equal(got, logits)
+    assert torch.equal(O.repetition_penalty(logits, gen, 1.0), logits) and torch.equal(O.repetition_penalty(logits, [], 1.3), logits)
 
 
 def test_true_dims_first_turn_matches_reference_fixture():
