@@ -173,9 +173,9 @@ public:
 
     // decode graph + probes.  The step graph holds the env's page-table pointer, so there is one set per env (a round-robin over several
     // envs through svln_generate replays instead of re-capturing); [0] = the whole step, [1] / [2] = the halves around the probed launch
-    // (captured only while the roofline probe is on).
+    // (captured only while the roofline probe is on); a run-ahead batch of several steps is one graph.
     bool use_graph = false;
-    struct GraphSet { hipGraphExec_t ex[3] = {nullptr, nullptr, nullptr}; };
+    struct GraphSet { std::unordered_map<int, hipGraphExec_t> ex; };     // key: steps (whole batch) | 1000 (head of a probed step) | 2000 + steps (its tail)
     std::vector<GraphSet> graphs;
     // per-turn truncation of the spliced rows (the reference's config.tokenizer_model_max_length, stream_video_vln.py:241-244); 0 = none
     int turn_row_limit = 0;
@@ -898,49 +898,58 @@ public:
                              probe_ev[probe_used + 1]);
         probe_used += 2;
     }
-    hipGraphExec_t capture(Env& e, int lo, int hi) {
+    // graph of: ops [lo, hi) of one decode step (+ the head when hi is the end of the step), then `more` further whole steps
+    hipGraphExec_t capture(Env& e, int lo, int hi, int more = 0) {
         hipGraph_t g; hipGraphExec_t ex;
         HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         decode_ops(e, lo, hi);
         if (hi == total_ops()) head(x, 0, true);       // (the tap row comes from the device)
+        for (int k = 0; k < more; ++k) { decode_ops(e, 0, total_ops()); head(x, 0, true); }
         HIP_CHECK(hipStreamEndCapture(st, &g));
         HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphDestroy(g));
         return ex;
     }
     void drop_graphs() {
-        for (auto& gs : graphs)
-            for (auto& g : gs.ex) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        for (auto& gs : graphs) {
+            for (auto& kv : gs.ex) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+            gs.ex.clear();
+        }
     }
-    // HIP events bracket the layer-0 gate/up GEMV (launched directly between two captured halves) while probing;
-    // that launch is the same kernel, grid and bytes as the other layers' gate/up GEMVs inside the graph.
-    // Enqueue one decode step (position, kv length and the fed token live in device memory: GenCtl / d_token); nothing here waits
-    // for the GPU, so several steps can be in flight behind one another.
-    void decode_step(Env& e, int env, int tap_row) {
+    // Enqueue `steps` decode steps (position, kv length and the fed token live in device memory: GenCtl / d_token); nothing here waits
+    // for the GPU.  With hipGraph replay the whole run-ahead batch is ONE graph launch (every launch of a ~175-node graph left a
+    // 50-70 us bubble in the kernel trace of round 2: four launches per turn).  The roofline probe times the layer-0 gate/up GEMV of
+    // the FIRST decode step of every turn: that step is split around one plain timed launch (same kernel, grid and bytes as the other
+    // layers' gate/up GEMVs inside the graph), the remaining steps ride in the second graph.
+    void decode_steps(Env& e, int env, int first_tap_row, int steps) {
+        if (steps <= 0) return;
         const int n_ops = total_ops();
-        // the roofline probe times the layer-0 gate/up GEMV of the FIRST decode step of every turn (a probed step runs as two graphs around a
-        // plain timed launch; the other steps replay the whole-step graph)
-        const bool probing = probe_on && tap_row == 1 && probe_used + 2 <= probe_ev.size();
+        const bool probing = probe_on && first_tap_row == 1 && probe_used + 2 <= probe_ev.size();
         if (use_graph) {
             GraphSet& gs = graphs[env];
+            auto get = [&](int key, int lo, int hi, int more) {
+                hipGraphExec_t& ex = gs.ex[key];
+                if (!ex) ex = capture(e, lo, hi, more);
+                return ex;
+            };
             if (!probing) {
-                if (!gs.ex[0]) gs.ex[0] = capture(e, 0, n_ops);
-                HIP_CHECK(hipGraphLaunch(gs.ex[0], st));
+                HIP_CHECK(hipGraphLaunch(get(steps, 0, n_ops, steps - 1), st));
             } else {
-                if (!gs.ex[1]) { gs.ex[1] = capture(e, 0, PROBE_OP); gs.ex[2] = capture(e, PROBE_OP + 1, n_ops); }
-                HIP_CHECK(hipGraphLaunch(gs.ex[1], st));
+                HIP_CHECK(hipGraphLaunch(get(1000, 0, PROBE_OP, 0), st));
                 probe_launch(e);
-                HIP_CHECK(hipGraphLaunch(gs.ex[2], st));
+                HIP_CHECK(hipGraphLaunch(get(2000 + steps, PROBE_OP + 1, n_ops, steps - 1), st));
             }
-        } else {
-            if (!probing) {
+            return;
+        }
+        for (int k = 0; k < steps; ++k) {
+            if (!(probing && k == 0)) {
                 decode_ops(e, 0, n_ops);
             } else {
                 decode_ops(e, 0, PROBE_OP);
                 probe_launch(e);
                 decode_ops(e, PROBE_OP + 1, n_ops);
             }
-            head(x, tap_row, true);
+            head(x, first_tap_row + k, true);
         }
     }
 
@@ -1294,10 +1303,10 @@ public:
             int steps = limit - enq;
             if (steps > RUN_AHEAD) steps = RUN_AHEAD;
             if (steps > c.max_positions - (L + enq - 1)) steps = c.max_positions - (L + enq - 1);       // step k feeds position L + enq - 1
-            for (int k = 0; k < steps; ++k) {
-                ensure_pages(e, L + enq);
-                decode_step(e, env, enq);
-                ++enq;
+            if (steps > 0) {
+                ensure_pages(e, L + enq + steps - 1);          // pages of every position the batch may write, before it is enqueued
+                decode_steps(e, env, enq, steps);
+                enq += steps;
                 decoded = true;
             }
             if (decoded) HIP_CHECK(hipEventRecord(ph_ev[4], st));

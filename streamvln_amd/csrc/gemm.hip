@@ -924,34 +924,34 @@ template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a) {
 }
 
 template <typename T, int EPI> static void gemm_attr() {
-    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg128, false>, 2 * Cfg128::STAGE_BYTES);
-    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg256, false>, 2 * Cfg256::STAGE_BYTES);
-    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg256, true>, 2 * Cfg256::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, Cfg128::NBUF * Cfg128::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, Cfg64::NBUF * Cfg64::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, CfgBig::NBUF * CfgBig::STAGE_BYTES);
+    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg128, false>, 2 * Cfg128::STAGE_BYTES, Cfg128::THREADS);
+    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg256, false>, 2 * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg256, true>, 2 * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, Cfg64::NBUF * Cfg64::STAGE_BYTES, Cfg64::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES, Cfg128L::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false, fp8_t>, Cfg64::NBUF * Cfg64::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false, fp8_t>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false, fp8_t>, CfgBig::NBUF * CfgBig::STAGE_BYTES);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false, fp8_t>, Cfg64::NBUF * Cfg64::STAGE_BYTES, Cfg64::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false, fp8_t>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES, Cfg128L::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false, fp8_t>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     }
 }
 void gemm_init_attrs() {

@@ -219,8 +219,17 @@ void preprocess_init_attrs();
 // raise the dynamic-LDS limit of the kernels that may ask for more than 64 KiB (call once, outside capture).  A refused attribute would
 // only show up later as a failed launch of that one kernel: the first refusal is kept and returned by init_kernel_attributes().
 inline hipError_t& attr_status() { static hipError_t e = hipSuccess; return e; }
-inline void set_max_lds(const void* fn, int bytes) {
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+// threads > 0: also check, on the host, that the code object accepts a block of that size (its max flat workgroup size comes from
+// __launch_bounds__): a launch above it -- or above the dynamic-LDS attribute -- is not reported by hipLaunchKernel; the packet
+// processor rejects the packet and the runtime aborts the process from its queue-error callback, with no message at the default log
+// level (the round-2 test_gemm abort).
+inline void set_max_lds(const void* fn, int bytes, int threads = 0) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && threads > 0) {
+        hipFuncAttributes at;
+        e = hipFuncGetAttributes(&at, fn);
+        if (e == hipSuccess && (at.maxThreadsPerBlock < threads || bytes > 160 * 1024)) e = hipErrorInvalidConfiguration;
+    }
     if (e != hipSuccess && attr_status() == hipSuccess) attr_status() = e;
 }
 void gemm_init_attrs();
