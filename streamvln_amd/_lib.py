@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstreamvln_hip.so")
+# SVLN_LIB: another build of the same engine (tools/ab_lib.sh: A/B of two builds on one GPU box); default = the in-tree library
+LIB_PATH = os.environ.get("SVLN_LIB") or os.path.join(_HERE, "libstreamvln_hip.so")
 
 SVLN_BF16, SVLN_F32 = 0, 1
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_SWIGLU, EPI_ARGMAX = 0, 1, 2, 3, 4

@@ -171,6 +171,9 @@ struct RopeKvArgs {
 };
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a);
 void launch_rope_table(hipStream_t s, float* tab, const float* inv_freq, int positions);
+// touch `bytes` of read-only memory with plain 16-byte loads (results discarded) so that they are resident in the Infinity Cache when
+// the next weight-streaming kernel asks for them; no-op when *skip != 0
+void launch_prefetch(hipStream_t s, const void* p, size_t bytes, const int* skip);
 // out[2f], out[2f+1] += 128-bit content key of frame f (caller zeroes `out` first)
 void launch_frame_hash(hipStream_t s, const float* pix, int F, size_t words_per_frame, unsigned long long* out);
 
