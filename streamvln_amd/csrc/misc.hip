@@ -357,6 +357,13 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const uint4* p, size_t n1
     }
     if (acc == 0x9E3779B9u && sink) *sink = acc;
 }
+int grid_for(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
 static unsigned* g_prefetch_sink = nullptr;
 void launch_prefetch(hipStream_t s, const void* p, size_t bytes, const int* skip) {
     const size_t n16 = bytes / 16;
@@ -366,12 +373,6 @@ void launch_prefetch(hipStream_t s, const void* p, size_t bytes, const int* skip
     hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)p, n16, skip, g_prefetch_sink);
 }
 
-int grid_for(int64_t n) {
-    int64_t g = (n + 255) / 256;
-    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
-}
-
-}  // namespace
 
 template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip,
                                           void* y2, const int* y2_row, int y2_cap) {
