@@ -120,8 +120,6 @@ public:
     svln_config c;
     int device;
     hipStream_t st = nullptr;
-    // side stream of the decode step: weight prefetch beside the attention launches (forked / joined with events, also inside the graph)
-    hipStream_t st2 = nullptr; hipEvent_t fork_ev = nullptr, join_ev = nullptr; int prefetch_mode = 0;
     std::vector<void*> allocs;
     std::unordered_map<std::string, Slot> slots;
 
@@ -209,10 +207,6 @@ public:
     Engine(const svln_config& cfg, int dev) : c(cfg), device(dev) {
         DeviceGuard guard(dev);
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
-        if (const char* pm = getenv("SVLN_PREFETCH")) prefetch_mode = atoi(pm);
         Hv = c.v_hidden; Iv = c.v_inter; vheads = c.v_heads; vhd = Hv / vheads; side = c.v_image / c.v_patch; S = side * side;
         kp = ((3 * c.v_patch * c.v_patch + 7) / 8) * 8;
         oside = (side + 1) / 2; otok = oside * oside;
@@ -391,9 +385,6 @@ public:
         if (h_pen_rows) (void)hipHostFree(h_pen_rows);
         if (h_pen_ids) (void)hipHostFree(h_pen_ids);
         (void)hipStreamDestroy(st);
-        if (st2) (void)hipStreamDestroy(st2);
-        if (fork_ev) (void)hipEventDestroy(fork_ev);
-        if (join_ev) (void)hipEventDestroy(join_ev);
         if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
 
@@ -892,23 +883,9 @@ public:
             const LLayer& L = ll[i];
             if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE), L.qkv8)));
             AttnArgs a = llm_attn_args(L, e, qkv, qkv_dim, attn, qd, 1, 0, 0, true);
-            bool forked = false;
-            if (on()) {
-                if (prefetch_mode > 0 && !fp8_on) {
-                    HIP_CHECK(hipEventRecord(fork_ev, st));
-                    HIP_CHECK(hipStreamWaitEvent(st2, fork_ev, 0));
-                    launch_prefetch(st2, L.o_w, (size_t)H * qd * sizeof(T), &d_ctl->done);
-                    if (prefetch_mode > 1) launch_prefetch(st2, L.gu_w, (size_t)(prefetch_mode - 1) * (4u << 20), &d_ctl->done);
-                    HIP_CHECK(hipEventRecord(join_ev, st2));
-                    forked = true;
-                }
-                launch_attention<T>(st, a, 128, 1);
-            }
+            if (on()) launch_attention<T>(st, a, 128, 1);
             if (on()) launch_attention_combine<T>(st, a, 128);
-            if (on()) {
-                if (forked) HIP_CHECK(hipStreamWaitEvent(st, join_ev, 0));
-                launch_gemv<T>(st, guarded(with8(gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE), L.o8)));
-            }
+            if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.o_w, qd, attn, nullptr, nullptr, x, x, H, qd, EPI_NONE), L.o8)));
             if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8)));
             if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.down_w, I, hbuf, nullptr, nullptr, x, x, H, I, EPI_NONE), L.down8)));
         }

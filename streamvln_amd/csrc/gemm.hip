@@ -31,22 +31,27 @@ namespace svln {
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false> struct TileCfg {
+template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1> struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ROWB = ROWB_;
+    // KG > 1: K is split INSIDE the workgroup: KG groups of WM x WN waves each run the stage pipeline (own LDS ring) over 1/KG of the K
+    // stages of the same output tile and exchange their accumulators through LDS at the end -- the shorter K chain of a split-K launch
+    // without fp32 slabs in HBM and without a second (reduce) launch
+    static constexpr int KG = KG_;
     static constexpr bool DEEP = DEEP_;
     static constexpr int NBUF = NBUF_;                        // LDS ring depth of the direct-to-LDS (glds) pipeline
     // ILV: the fragment reads of macro step s+1 are issued one per gap between the MFMAs of step s instead of as one burst before
     // them (measured: 4-6 % faster when a CU runs many tiles back to back, slower for single-round launches with short K)
     static constexpr bool ILV = ILV_;
-    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int THREADS = 64 * WM * WN * KG;
     static constexpr int CH = ROWB / 16;                      // 16-byte chunks per row per stage
     static constexpr int ROWS_PER_BANKROW = 256 / ROWB;       // 2 or 4
     static constexpr int SH = ROWS_PER_BANKROW == 2 ? 1 : 2;
     static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-    static constexpr int A_LOADS = BM * CH / THREADS, W_LOADS = BN * CH / THREADS;
+    static constexpr int A_LOADS = BM * CH / (THREADS / KG), W_LOADS = BN * CH / (THREADS / KG);
+    static constexpr int LDS_BYTES = KG * NBUF * STAGE_BYTES;
     static constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;   // 32x32 accumulator tiles per wave
     static_assert(BM / WM % 32 == 0 && BN / WN % 64 == 0, "wave tile: rows a multiple of 32, columns a multiple of 64 ([gate 32 | up 32] blocks for SwiGLU)");
-    static_assert(BM * CH % THREADS == 0 && BN * CH % THREADS == 0, "staging must divide evenly");
+    static_assert(BM * CH % (THREADS / KG) == 0 && BN * CH % (THREADS / KG) == 0, "staging must divide evenly");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
@@ -54,6 +59,8 @@ using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
 using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
                                                              // products with few 128-wide column tiles and a short K (force_cfg 64 only, see launch_epi)
+using Cfg128K2 = TileCfg<128, 128, 2, 2, 128, false, 2, false, 2>;   // 128x128 tile, 2 K-groups of 4 waves (128 KB of LDS: one workgroup per CU): one-round launches with a
+                                                             // short K and an epilogue that wants the finished value (one-frame ViT qkv / fc1, projector)
 using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockstep decode of several envs): 2 waves, 20 KB stages, glds kernel only
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
@@ -270,15 +277,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
     constexpr bool FP8 = sizeof(TA) == 1;
     static_assert(C::ROWB == 128 && C::CH == 8, "glds path: 128-byte tile rows (4 macro steps per stage)");
-    constexpr int WAVES = C::THREADS / 64;
+    constexpr int KG = C::KG;
+    constexpr int WAVES = C::THREADS / 64 / KG;               // waves of one K-group
     constexpr int BLK_A = C::BM * C::ROWB / 1024, BLK_W = C::BN * C::ROWB / 1024;
     constexpr int PER_WAVE = (BLK_A + BLK_W) / WAVES;
     constexpr int D = C::NBUF - 1;
     static_assert((BLK_A + BLK_W) % WAVES == 0, "blocks must divide over waves");
     static_assert(!NTW || BLK_A % WAVES == 0, "NTW: a wave's blocks must be all-activation or all-weight per index");
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    static_assert(KG == 1 || (!SPLITK && C::MI % KG == 0), "in-workgroup K groups: unsplit launches, each group finishes MI / KG accumulator rows");
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = KG > 1 ? wave_all / WAVES : 0, wave = KG > 1 ? wave_all % WAVES : wave_all;
     const int wr = wave / C::WN, wc = wave % C::WN;
     const int r32 = lane & 31, h = lane >> 5;
+    char* const ring = smem + (KG > 1 ? kg * C::NBUF * C::STAGE_BYTES : 0);      // this K-group's stage ring
 
     const int tiles_m = (p.M + C::BM - 1) / C::BM;
     const int nsplit = SPLITK ? p.nsplit : 1;
@@ -295,9 +306,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     const int kchunks = p.K / EPC;
     const int stages_total = (kchunks + C::CH - 1) / C::CH;
     const int stages_per = (stages_total + nsplit - 1) / nsplit;
-    const int st_begin = ks * stages_per;
-    const int st_end = min(stages_total, st_begin + stages_per);
-    const int n = st_end - st_begin;
+    int st_begin = ks * stages_per;
+    int st_end = min(stages_total, st_begin + stages_per);
+    int n_it = st_end - st_begin;                                                // barrier-uniform iteration count of the stage loop
+    if (KG > 1) {                                                                // this K-group's share of the workgroup's stages
+        const int per = (n_it + KG - 1) / KG;
+        st_begin += kg * per;
+        st_end = min(st_end, st_begin + per);
+        n_it = per;
+    }
+    const int n = max(st_end - st_begin, 0);
 
     // per-lane source pointers (at K stage 0) and wave-uniform LDS offsets of this wave's 1-KiB blocks
     const char* src[PER_WAVE];
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
     }
     auto issue = [&](int st, int buf) {
-        char* base = smem + buf * C::STAGE_BYTES;
+        char* base = ring + buf * C::STAGE_BYTES;
         const bool full = (st + 1) * C::CH <= kchunks;
         if (full) {                       // every stage but a ragged last one: no per-lane source select in front of the DMA instructions
 #pragma unroll
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     // LDS fragment reads are issued as inline asm: hipcc orders every ds_read it can see behind ALL outstanding
     // LDS-DMA (it emits s_waitcnt vmcnt(0) before the first ds_read of the stage, draining the ring); the asm reads are
     // ordered by our own protocol instead (counted vmcnt + barrier above, lgkmcnt waits tied to the destinations below).
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
     unsigned offA[STEPS][MI], offW[STEPS][NJ];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -441,23 +459,62 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     for (int d = 0; d < D; ++d)
         if (d < n) issue(st_begin + d, d);
     int buf = 0, nbuf = D % C::NBUF;              // buffer of stage i / of stage i + D
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n_it; ++i) {
         if (i + D <= n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (KG > 1 && i >= n) continue;               // a K-group with one stage less keeps the barrier count of the others
         compute(buf, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
     }
+    if constexpr (KG > 1) {
+        // Exchange between the two K-groups: group g finishes accumulator rows i with i / (MI / KG) == g, so it hands the OTHER rows to its
+        // partner wave (same wave tile, same lane -> same (m, n) mapping: no transposition) through LDS and adds the partner's copy of its
+        // own rows.  Every DMA has landed (vmcnt(0) above) and every fragment read has been consumed by an MFMA.
+        static_assert(KG == 2, "two K-groups");
+        constexpr int MH = MI / KG;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* xch = (float*)smem;                    // [K-group][wave][MH * NJ tiles][4 quads][64 lanes][4]
+        float* mine = xch + (size_t)((kg * WAVES + wave) * MH * NJ) * 1024;
+        const float* theirs = xch + (size_t)(((1 - kg) * WAVES + wave) * MH * NJ) * 1024;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i / MH == kg) continue;               // (wave-uniform; i stays a compile-time index)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *(float4*)(mine + (size_t)(((i % MH) * NJ + j) * 4 + q4) * 256 + lane * 4) =
+                        make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i / MH != kg) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 t = *(const float4*)(theirs + (size_t)(((i % MH) * NJ + j) * 4 + q4) * 256 + lane * 4);
+                    acc[i][j][4 * q4] += t.x; acc[i][j][4 * q4 + 1] += t.y; acc[i][j][4 * q4 + 2] += t.z; acc[i][j][4 * q4 + 3] += t.w;
+                }
+        }
+    }
+    // accumulator rows this wave stores (all of them without K-groups)
+    auto mine_i = [&](int i) { return KG == 1 || i / (MI / KG) == kg; };
 
     if (FP8) {           // dequantise (linear, so split-K partials are scaled too): per-row activation scale x per-row weight scale
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const float sw = p.w_scale[min(col0 + wc * WCOLS + j * 32 + r32, p.N - 1)];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                if (!mine_i(i)) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= sw * p.a_scale[min(row0 + wr * WROWS + i * 32 + acc_row(r, lane), p.M - 1)];
+            }
         }
     }
     if (SPLITK) {
@@ -485,22 +542,34 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             const int n_out = ((col0 + wc * WCOLS + jp * 64) >> 1) + r32;
             const bool ok_n = (col0 + wc * WCOLS + jp * 64 + 32 + r32) < p.N;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                if (!mine_i(i)) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
                     if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][2 * jp][r]) * acc[i][2 * jp + 1][r]);
                 }
+            }
         }
         return;
     }
+    // fused tail of the SigLIP QKV product (p.vp_on; same values and layout as splitk_qkv_vitpack_kernel / vit_kv_pack_kernel): the k columns
+    // also go to the K page of their (64-key tile, frame, head), the v columns transposed to the V^T page.  Padding channels and the
+    // keys past S of the last tile are never written: the pools are zero-filled at allocation and every writer leaves zeros there.
+    const VitPackArgs& vp = p.vp;
+    constexpr int EPC_T = Elt<T>::PER_CHUNK;
+    const int vHD = vp.head_dim, vHv = vp.heads * vHD, vHDP = ((((vHD + EPC_T - 1) / EPC_T) + 1) & ~1) * EPC_T, vVR = ((vHD + 31) / 32) * 32;
+    const int v_nkv = vp.F * vp.heads;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        if (!mine_i(i)) continue;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int nn = col0 + wc * WCOLS + j * 32 + r32;
             if (nn >= p.N) continue;
             const float bv = bias ? to_f32(bias[nn]) : 0.0f;
+            int part = 0, head = 0, dd = 0;
+            if (EPI == EPI_NONE && p.vp_on) { part = nn / vHv; const int w_ = nn - part * vHv; head = w_ / vHD; dd = w_ - head * vHD; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
@@ -510,9 +579,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                     const int rr = p.res_mod > 0 ? m % p.res_mod : m;
                     v += to_f32(res[(size_t)rr * p.ldr + nn]);
                 }
-                Cc[(size_t)m * p.ldc + nn] = from_f32<T>(v);
+                const T tv = from_f32<T>(v);
+                Cc[(size_t)m * p.ldc + nn] = tv;
+                if (EPI == EPI_NONE && p.vp_on && part > 0) {
+                    const int f = m / vp.S, srow = m - f * vp.S, tile = srow >> 6, key = srow & 63;
+                    const size_t pg = (size_t)tile * v_nkv + (size_t)f * vp.heads + head;
+                    if (part == 1) ((T*)vp.Kpool)[(pg * 64 + key) * vHDP + dd] = tv;
+                    else ((T*)vp.Vpool)[(pg * vVR + dd) * 64 + key] = tv;
+                }
             }
         }
+    }
 }
 
 // sum split-K slabs + epilogue.  One thread = 4 consecutive output columns of one row.
@@ -748,7 +825,7 @@ __global__ __launch_bounds__(256) void splitk_qkv_vitpack_kernel(GemmArgs p, Vit
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
-    if constexpr (C::MI == 2 && C::NJ == 2) {
+    if constexpr (C::MI == 2 && C::NJ == 2 && C::KG == 1) {
         if ((!a.zeros || (a.force_cfg & 0x2000)) && !a.a_scale) {          // register-staged kernel (64x64 wave tiles only; bf16 / fp32 operands)
             hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
             return;
@@ -759,21 +836,21 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
             if constexpr (HAS_NTW) {
                 if (a.nt_w) {
-                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
                     return;
                 }
             }
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
             return;
         }
     }
     if constexpr (HAS_NTW) {
         if (a.nt_w) {
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
             return;
         }
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::NBUF * C::STAGE_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
 }
 
 template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_t s, GemmArgs a, int S) {
@@ -806,6 +883,7 @@ template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_
 
 template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return false;
+    a.vp_on = 0;
     a.nt_w = a.M <= 256 ? 1 : 0;          // the heuristics below give such products ONE row tile (256x128 or 32x128 tiles)
     const int EPC = a.a_scale ? 16 : Elt<T>::PER_CHUNK;      // 16-byte chunks of K: e4m3 operands hold 16 values per chunk
     a.tile_base = 0;
@@ -861,6 +939,21 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         a.launch_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
         launch_cfg<T, EPI, Cfg64, false>(s, a, 1);
         return false;
+    }
+    // One round (or less) of 128x128 tiles over more than one row tile, with an epilogue that needs the finished value and no norm
+    // fused into a slab reduce -- the one-frame ViT qkv (K / V^T packing) and fc1 (GELU), the projector products: two K-groups inside the
+    // workgroup (Cfg128K2) instead of a K split over workgroups + fp32 slabs + a reduce launch.
+    const int stages128 = (a.K / EPC + Cfg128::CH - 1) / Cfg128::CH;
+    const bool kgroups = a.zeros && !(a.force_cfg & 0x2000) && a.force_split == 0 &&
+                         ((fc == 0 && a.M > 256 && tiles128 >= 96 && tiles128 <= 256 && stages128 >= 8 && !a.norm_out && !a.rope) || fc == 129);
+    if (kgroups) {
+        a.nsplit = 1;
+        a.launch_tiles = tiles128;
+        if (EPI == EPI_NONE && a.vitpack && !a.res && a.N == 3 * a.vitpack->heads * a.vitpack->head_dim && a.M == a.vitpack->F * a.vitpack->S) {
+            a.vp = *a.vitpack; a.vp_on = 1;
+        }
+        launch_cfg<T, EPI, Cfg128K2, false>(s, a, 1);
+        return a.vp_on != 0;
     }
     const bool want128 = a.M > 256 && tiles128 >= 256;
     if ((want128 && a.force_split == 0) || fc == 128) {
@@ -938,6 +1031,7 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, Cfg64::NBUF * Cfg64::STAGE_BYTES, Cfg64::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES, Cfg128L::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128K2, false>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);
@@ -951,6 +1045,7 @@ template <typename T, int EPI> static void gemm_attr() {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false, fp8_t>, Cfg64::NBUF * Cfg64::STAGE_BYTES, Cfg64::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false, fp8_t>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES, Cfg128L::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128K2, false, fp8_t>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false, fp8_t>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     }
 }

@@ -45,7 +45,8 @@ struct GemmArgs {
     // opt-in fp8 (OCP e4m3) operands (bf16 engine): when a_scale is set, A [M][K] and W [N][K] are e4m3 bytes (lda / ldw in
     // elements), C = a_scale[m] * w_scale[n] * (A . W^T) then the usual epilogue in bf16; K % 16 == 0
     const float* a_scale; const float* w_scale;
-    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
+    VitPackArgs vp; int vp_on;    // filled by the launcher: device-side copy of *vitpack for the unsplit kernels that pack in their epilogue
+    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 129 -> 128x128 tiles with two in-workgroup K groups; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced
 
@@ -171,9 +172,6 @@ struct RopeKvArgs {
 };
 template <typename T> void launch_rope_kv(hipStream_t s, const RopeKvArgs& a);
 void launch_rope_table(hipStream_t s, float* tab, const float* inv_freq, int positions);
-// touch `bytes` of read-only memory with plain 16-byte loads (results discarded) so that they are resident in the Infinity Cache when
-// the next weight-streaming kernel asks for them; no-op when *skip != 0
-void launch_prefetch(hipStream_t s, const void* p, size_t bytes, const int* skip);
 // out[2f], out[2f+1] += 128-bit content key of frame f (caller zeroes `out` first)
 void launch_frame_hash(hipStream_t s, const float* pix, int F, size_t words_per_frame, unsigned long long* out);
 

@@ -344,19 +344,6 @@ template <typename T> __global__ void from_f32_kernel(const float* s, T* d, int6
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = from_f32<T>(s[i]);
 }
 
-// Weight prefetch beside the decode attention (a forked graph branch): the attention / merge launches of a decode step leave HBM idle
-// for ~11 us per layer; this kernel pulls the o_proj weights of the layer through the memory side (Infinity Cache, 256 MiB, shared by
-// the 8 XCDs) meanwhile.  Each thread reads 16 B per step with the default cache policy; the sum is written only if it is a value no
-// sum of loads produces (keeps the loads alive without a store).
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* p, size_t n16, const int* skip, unsigned* sink) {
-    if (skip && *skip) return;
-    unsigned acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-        const uint4 v = p[i];
-        acc |= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9E3779B9u && sink) *sink = acc;
-}
 int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -364,14 +351,6 @@ int grid_for(int64_t n) {
 
 }  // namespace
 
-static unsigned* g_prefetch_sink = nullptr;
-void launch_prefetch(hipStream_t s, const void* p, size_t bytes, const int* skip) {
-    const size_t n16 = bytes / 16;
-    if (!n16) return;
-    int grid = (int)((n16 + 256 * 8 - 1) / (256 * 8));      // 8 loads (128 B) per thread
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)p, n16, skip, g_prefetch_sink);
-}
 
 
 template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip,
