@@ -271,7 +271,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // Rows beyond M / N are clamped to the last valid row (their outputs are never stored); K-tail chunks read a zero line.
 // NTW: the weight tile is staged with non-temporal LDS-DMA (products with ONE row tile: every weight byte is read once, by one workgroup).
 // A template parameter, not a run-time flag: a branch around the DMA issue of the large-tile kernels cost the window-restart prefill 2.5 ms.
-template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false>
+// VP: the fused K / V^T packing tail of the SigLIP QKV product (a template parameter: as a run-time flag its tests sat in the store loop of
+// every plain epilogue and cost the window-restart turn 2.8 ms).
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
@@ -553,13 +555,40 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
         return;
     }
-    // fused tail of the SigLIP QKV product (p.vp_on; same values and layout as splitk_qkv_vitpack_kernel / vit_kv_pack_kernel): the k columns
-    // also go to the K page of their (64-key tile, frame, head), the v columns transposed to the V^T page.  Padding channels and the
-    // keys past S of the last tile are never written: the pools are zero-filled at allocation and every writer leaves zeros there.
-    const VitPackArgs& vp = p.vp;
-    constexpr int EPC_T = Elt<T>::PER_CHUNK;
-    const int vHD = vp.head_dim, vHv = vp.heads * vHD, vHDP = ((((vHD + EPC_T - 1) / EPC_T) + 1) & ~1) * EPC_T, vVR = ((vHD + 31) / 32) * 32;
-    const int v_nkv = vp.F * vp.heads;
+    if constexpr (VP) {
+        // fused tail of the SigLIP QKV product (same values and layout as splitk_qkv_vitpack_kernel / vit_kv_pack_kernel): the k columns also
+        // go to the K page of their (64-key tile, frame, head), the v columns transposed to the V^T page.  Padding channels and the keys past
+        // S of the last tile are never written: the pools are zero-filled at allocation and every writer leaves zeros there.
+        const VitPackArgs& vp = p.vp;
+        constexpr int EPC_T = Elt<T>::PER_CHUNK;
+        const int vHD = vp.head_dim, vHv = vp.heads * vHD, vHDP = ((((vHD + EPC_T - 1) / EPC_T) + 1) & ~1) * EPC_T, vVR = ((vHD + 31) / 32) * 32;
+        const int v_nkv = vp.F * vp.heads;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (!mine_i(i)) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nn = col0 + wc * WCOLS + j * 32 + r32;
+                if (nn >= p.N) continue;
+                const float bv = bias ? to_f32(bias[nn]) : 0.0f;
+                const int part = nn / vHv, w_ = nn - part * vHv, head = w_ / vHD, dd = w_ - head * vHD;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
+                    if (m >= p.M) continue;
+                    const T tv = from_f32<T>(acc[i][j][r] + bv);
+                    Cc[(size_t)m * p.ldc + nn] = tv;
+                    if (part > 0) {
+                        const int f = m / vp.S, srow = m - f * vp.S, tile = srow >> 6, key = srow & 63;
+                        const size_t pg = (size_t)tile * v_nkv + (size_t)f * vp.heads + head;
+                        if (part == 1) ((T*)vp.Kpool)[(pg * 64 + key) * vHDP + dd] = tv;
+                        else ((T*)vp.Vpool)[(pg * vVR + dd) * 64 + key] = tv;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         if (!mine_i(i)) continue;
@@ -568,8 +597,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             const int nn = col0 + wc * WCOLS + j * 32 + r32;
             if (nn >= p.N) continue;
             const float bv = bias ? to_f32(bias[nn]) : 0.0f;
-            int part = 0, head = 0, dd = 0;
-            if (EPI == EPI_NONE && p.vp_on) { part = nn / vHv; const int w_ = nn - part * vHv; head = w_ / vHD; dd = w_ - head * vHD; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = row0 + wr * WROWS + i * 32 + acc_row(r, lane);
@@ -579,14 +606,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                     const int rr = p.res_mod > 0 ? m % p.res_mod : m;
                     v += to_f32(res[(size_t)rr * p.ldr + nn]);
                 }
-                const T tv = from_f32<T>(v);
-                Cc[(size_t)m * p.ldc + nn] = tv;
-                if (EPI == EPI_NONE && p.vp_on && part > 0) {
-                    const int f = m / vp.S, srow = m - f * vp.S, tile = srow >> 6, key = srow & 63;
-                    const size_t pg = (size_t)tile * v_nkv + (size_t)f * vp.heads + head;
-                    if (part == 1) ((T*)vp.Kpool)[(pg * 64 + key) * vHDP + dd] = tv;
-                    else ((T*)vp.Vpool)[(pg * vVR + dd) * 64 + key] = tv;
-                }
+                Cc[(size_t)m * p.ldc + nn] = from_f32<T>(v);
             }
         }
     }
@@ -952,8 +972,15 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         if (EPI == EPI_NONE && a.vitpack && !a.res && a.N == 3 * a.vitpack->heads * a.vitpack->head_dim && a.M == a.vitpack->F * a.vitpack->S) {
             a.vp = *a.vitpack; a.vp_on = 1;
         }
+        if constexpr (EPI == EPI_NONE) {
+            if (a.vp_on && !a.a_scale) {
+                hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_NONE, Cfg128K2, false, T, false, true>), dim3(tiles128), dim3(Cfg128K2::THREADS), Cfg128K2::LDS_BYTES, s, a);
+                return true;
+            }
+        }
+        a.vp_on = 0;
         launch_cfg<T, EPI, Cfg128K2, false>(s, a, 1);
-        return a.vp_on != 0;
+        return false;
     }
     const bool want128 = a.M > 256 && tiles128 >= 256;
     if ((want128 && a.force_split == 0) || fc == 128) {
@@ -1032,6 +1059,7 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, Cfg64::NBUF * Cfg64::STAGE_BYTES, Cfg64::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES, Cfg128L::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128K2, false>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
+    if constexpr (EPI == EPI_NONE) set_max_lds((const void*)gemm_glds_kernel<T, EPI_NONE, Cfg128K2, false, T, false, true>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);
