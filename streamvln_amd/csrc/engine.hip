@@ -177,6 +177,7 @@ public:
     bool use_graph = false;
     struct GraphSet { std::unordered_map<int, hipGraphExec_t> ex; };     // key: steps (whole batch) | 1000 (head of a probed step) | 2000 + steps (its tail)
     std::vector<GraphSet> graphs;
+    std::unordered_map<int, hipGraphExec_t> bgraphs;          // batched decode step: key = B | penalty << 8 | fp8 gemm << 9
     // per-turn truncation of the spliced rows (the reference's config.tokenizer_model_max_length, stream_video_vln.py:241-244); 0 = none
     int turn_row_limit = 0;
     // HF repetition penalty of the checkpoint's generation_config (1 = off): flags of the tokens generated in the current turn
@@ -915,6 +916,8 @@ public:
             for (auto& kv : gs.ex) if (kv.second) (void)hipGraphExecDestroy(kv.second);
             gs.ex.clear();
         }
+        for (auto& kv : bgraphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        bgraphs.clear();
     }
     // Enqueue `steps` decode steps (position, kv length and the fed token live in device memory: GenCtl / d_token); nothing here waits
     // for the GPU.  With hipGraph replay the whole run-ahead batch is ONE graph launch (every launch of a ~175-node graph left a
@@ -961,12 +964,25 @@ public:
     }
     // final norm of rows[0..B) -> lm_head once for all B envs -> d_tok_b[0..B)
     // pen: the repetition penalty is on and d_pen_rows[0..B) holds the job slot (= flag row) of every batch row
-    void head_batched(const T* rows, int B, bool pen = false) {
-        launch_rmsnorm<T>(st, rows, final_norm, xn, B, H, c.rms_eps);
-        GemvBatchArgs hb = gemvb_args(lm_head, H, xn, H, nullptr, nullptr, nullptr, 0, nullptr, 0, V, H, EPI_ARGMAX, B);
+    // arg-max over W [N][K] . x_b for B rows -> d_tok_b.  B >= 4: one pass of 32-row MFMA tiles with the arg-max in the epilogue (the
+    // batched GEMV is dot-product-issue bound from B = 4: 386 us at B = 8 on the full vocabulary); B <= 2: the batched GEMV.
+    void argmax_rows(const void* W, int ldw, const T* xrows, int ldx, int N, int K, int B, bool pen) {
+        if (B >= batched_mfma_min && K % Elt<T>::PER_CHUNK == 0 && (N + 127) / 128 <= 2048) {
+            GemmArgs a = gemm_args(xrows, ldx, W, ldw, nullptr, 0, nullptr, nullptr, 0, 0, B, N, K, EPI_ARGMAX);
+            a.part_val = part_val_b; a.part_idx = part_idx_b;
+            if (pen) { a.pen_flags = pen_flags_b; a.pen_rows = d_pen_rows; a.pen = rep_penalty; }
+            const int n = launch_gemm_argmax<T>(st, a);
+            launch_argmax_final_batched(st, part_val_b, part_idx_b, n, B, d_tok_b);
+            return;
+        }
+        GemvBatchArgs hb = gemvb_args(W, ldw, xrows, ldx, nullptr, nullptr, nullptr, 0, nullptr, 0, N, K, EPI_ARGMAX, B);
         if (pen) { hb.pen_flags = pen_flags_b; hb.pen_rows = d_pen_rows; hb.pen = rep_penalty; }
         launch_gemv_batched<T>(st, hb);
-        launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(V, EPI_ARGMAX, B), B, d_tok_b);
+        launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(N, EPI_ARGMAX, B), B, d_tok_b);
+    }
+    void head_batched(const T* rows, int B, bool pen = false) {
+        launch_rmsnorm<T>(st, rows, final_norm, xn, B, H, c.rms_eps);
+        argmax_rows(lm_head, H, xn, H, V, H, B, pen);
     }
     // One decode step for B envs (B in {1,2,4,8}; d_slots / d_tok_b already set): every weight matrix is streamed once.
     // B >= 4: the projections run as 32-row MFMA products (gemm.hip CfgSkinny: the weight stream goes through LDS-DMA, the B rows
@@ -1150,7 +1166,23 @@ public:
             HIP_CHECK(hipMemcpyAsync(d_tok_b, h_tok_b, B * sizeof(int), hipMemcpyHostToDevice, st));
             if (segs.empty()) {
                 if (pen) HIP_CHECK(hipMemcpyAsync(d_pen_rows, h_pen_rows, B * sizeof(int), hipMemcpyHostToDevice, st));
-                decode_ops_batched(B, pen);              // gather + 28 layers + head for B decode rows -> d_tok_b, xn = final-norm rows
+                // gather + 28 layers + head for B decode rows -> d_tok_b, xn = final-norm rows.  With hipGraph replay on, the step of each
+                // (B, fp8, penalty) combination is captured once: every run-time value (page tables, positions, fed tokens) is in d_slots / d_tok_b.
+                if (use_graph) {
+                    const int key = B | (pen ? 256 : 0) | (fp8_gemm_on ? 512 : 0);
+                    hipGraphExec_t& ex = bgraphs[key];
+                    if (!ex) {
+                        hipGraph_t g;
+                        HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                        decode_ops_batched(B, pen);
+                        HIP_CHECK(hipStreamEndCapture(st, &g));
+                        HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+                        HIP_CHECK(hipGraphDestroy(g));
+                    }
+                    HIP_CHECK(hipGraphLaunch(ex, st));
+                } else {
+                    decode_ops_batched(B, pen);
+                }
             } else {
                 launch_gather_rows<T>(st, d_tok_b, embed, feats, x, nd, H);
             }
@@ -1513,9 +1545,10 @@ public:
         REQUIRE(a.K % Elt<T>::PER_CHUNK == 0 && a.N >= 1, "bad GEMV extents");
         REQUIRE(a.epi != EPI_SWIGLU || a.N % 64 == 0, "SwiGLU needs N % 64 == 0 (32-row gate / up blocks)");
         a.part_val = part_val_b; a.part_idx = part_idx_b;
-        launch_gemv_batched<T>(st, a);
+        if (a.epi == EPI_ARGMAX && !a.norm_w) argmax_rows(a.W, a.ldw, (const T*)a.x, a.ldx, a.N, a.K, a.B, false);      // the engine's own routing (MFMA tiles from B = 4)
+        else launch_gemv_batched<T>(st, a);
         if (a.epi == EPI_ARGMAX) {
-            launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(a.N, EPI_ARGMAX, a.B), a.B, d_tok_b);
+            if (a.norm_w) launch_argmax_final_batched(st, part_val_b, part_idx_b, gemv_batched_grid(a.N, EPI_ARGMAX, a.B), a.B, d_tok_b);
             HIP_CHECK(hipMemcpyAsync(h_tok_b, d_tok_b, a.B * sizeof(int), hipMemcpyDeviceToHost, st));
             sync();
             if (host_tokens) for (int b = 0; b < a.B; ++b) host_tokens[b] = h_tok_b[b];

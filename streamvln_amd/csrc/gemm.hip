@@ -65,6 +65,8 @@ using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockste
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
 
+constexpr int EPI_ARGMAX_ = 4;
+static_assert(EPI_ARGMAX_ == EPI_ARGMAX, "enum");
 template <typename T, int EPI> SVLN_DEV float epi_act(float v) {
     if (EPI == EPI_GELU_TANH) return gelu_tanh_f(v);
     if (EPI == EPI_GELU_ERF) return gelu_erf_f(v);
@@ -533,6 +535,53 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                     if (m < p.M) slab[(size_t)m * p.N + nn] = acc[i][j][r];
                 }
             }
+        return;
+    }
+    if constexpr (EPI == EPI_ARGMAX) {
+        // Arg-max epilogue (lm_head of several envs decoded together): row m of the tile keeps (greatest logit, lowest column) over the
+        // tile's columns.  Lane r32 holds column j * 32 + r32 of 16 rows: reduce over j in the lane, over the 32 lanes of a half with
+        // xor-shuffles (the halves hold different rows), then over the WN waves through LDS.  First-max-wins needs the index compare
+        // because the shuffle tree does not visit columns in order.
+        static_assert(MI == 1 && KG == 1 && !SPLITK, "arg-max epilogue: 32-row tiles, unsplit");
+        float bv[16]; int bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(row0 + acc_row(r, lane), p.M - 1);
+            const uint8_t* fl = p.pen_flags ? p.pen_flags + (size_t)p.pen_rows[m] * p.N : nullptr;
+            float v = -INFINITY; int vi = 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nn = col0 + wc * WCOLS + j * 32 + r32;
+                float c = acc[0][j][r];
+                if (fl && nn < p.N && fl[nn]) c = c < 0.0f ? c * p.pen : c / p.pen;
+                if (nn < p.N && (c > v || (c == v && nn < vi))) { v = c; vi = nn; }
+            }
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(vi, o, 64);
+                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            }
+            bv[r] = v; bi[r] = vi;
+        }
+        __syncthreads();                                   // every wave is done with the stage ring: reuse its first bytes
+        float* sv = (float*)smem; int* si = (int*)(smem + C::WN * 32 * sizeof(float));
+        if (r32 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sv[wc * 32 + acc_row(r, lane)] = bv[r]; si[wc * 32 + acc_row(r, lane)] = bi[r]; }
+        }
+        __syncthreads();
+        if (tid < 32 && row0 + tid < p.M) {
+            float v = sv[tid]; int vi = si[tid];
+#pragma unroll
+            for (int w = 1; w < C::WN; ++w) {
+                const float ov = sv[w * 32 + tid]; const int oi = si[w * 32 + tid];
+                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            }
+            const int tiles_n = p.launch_tiles;            // (one row tile: launch_tiles = column tiles)
+            p.part_val[(size_t)(row0 + tid) * tiles_n + bn] = v;
+            p.part_idx[(size_t)(row0 + tid) * tiles_n + bn] = vi;
+        }
         return;
     }
     T* Cc = (T*)p.C;
@@ -1032,6 +1081,17 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
 
 }  // namespace
 
+// lm_head of <= 32 rows (envs decoded together) with the arg-max in the epilogue: one pass of 32x128 tiles over the vocabulary, the weight
+// tile staged non-temporally, no C.  Returns the number of column tiles (= partials per row).
+template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a) {
+    a.nt_w = 1; a.tile_base = 0; a.nsplit = 1; a.vp_on = 0;
+    a.launch_tiles = (a.N + 127) / 128;
+    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
+    return a.launch_tiles;
+}
+template int launch_gemm_argmax<bf16>(hipStream_t, GemmArgs);
+template int launch_gemm_argmax<float>(hipStream_t, GemmArgs);
+
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a) {
     switch (a.epi) {
         case EPI_NONE: return launch_epi<T, EPI_NONE>(s, a);
@@ -1077,7 +1137,11 @@ template <typename T, int EPI> static void gemm_attr() {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false, fp8_t>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     }
 }
+template <typename T> static void gemm_argmax_attr() {
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
+}
 void gemm_init_attrs() {
+    gemm_argmax_attr<bf16>(); gemm_argmax_attr<float>();
     gemm_attr<bf16, EPI_NONE>(); gemm_attr<bf16, EPI_GELU_TANH>(); gemm_attr<bf16, EPI_GELU_ERF>(); gemm_attr<bf16, EPI_SWIGLU>();
     gemm_attr<float, EPI_NONE>(); gemm_attr<float, EPI_GELU_TANH>(); gemm_attr<float, EPI_GELU_ERF>(); gemm_attr<float, EPI_SWIGLU>();
 }

@@ -45,10 +45,16 @@ struct GemmArgs {
     // opt-in fp8 (OCP e4m3) operands (bf16 engine): when a_scale is set, A [M][K] and W [N][K] are e4m3 bytes (lda / ldw in
     // elements), C = a_scale[m] * w_scale[n] * (A . W^T) then the usual epilogue in bf16; K % 16 == 0
     const float* a_scale; const float* w_scale;
+    // EPI_ARGMAX (M <= 32 rows, 32x128 tiles, no K split: the lm_head of several envs decoded together): no C; row m's (max, lowest index)
+    // over the 128 columns of tile t goes to part_val / part_idx [m][tiles], reduced by launch_argmax_final_batched.  Optional repetition
+    // penalty as in GemvBatchArgs.
+    float* part_val = nullptr; int* part_idx = nullptr;
+    const uint8_t* pen_flags = nullptr; const int* pen_rows = nullptr; float pen = 1.0f;
     VitPackArgs vp; int vp_on;    // filled by the launcher: device-side copy of *vitpack for the unsplit kernels that pack in their epilogue
     int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 129 -> 128x128 tiles with two in-workgroup K groups; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced
+template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a);    // EPI_ARGMAX form (M <= 32); returns the partials per row
 
 // y[N] = epi(W[N,K] . x'[K] + bias) + res,  x' = x or rmsnorm(x) * norm_w (fused prologue).
 // EPI_SWIGLU as above (y has N/2 entries).  EPI_ARGMAX: no y; per-workgroup (max, lowest index)
