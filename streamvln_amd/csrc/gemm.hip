@@ -31,12 +31,18 @@ namespace svln {
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1> struct TileCfg {
+template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1, int NA_ = 0, int NW_ = 0> struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ROWB = ROWB_;
     // KG > 1: K is split INSIDE the workgroup: KG groups of WM x WN waves each run the stage pipeline (own LDS ring) over 1/KG of the K
     // stages of the same output tile and exchange their accumulators through LDS at the end -- the shorter K chain of a split-K launch
     // without fp32 slabs in HBM and without a second (reduce) launch
     static constexpr int KG = KG_;
+    // NA, NW > 0: ASYMMETRIC rings (single-row-tile products, M <= 256): the activation tile (L2-resident, re-read by every column tile)
+    // and the weight tile (streamed from HBM once) get separate LDS rings of NA and NW buffers, and separate loader waves (half of the
+    // waves issue only weight pieces, the other half only activation pieces), so each keeps its own counted vmcnt: NW - 1 weight stages
+    // stay in flight (64 KB per CU instead of 32 KB with the shared 3-deep ring) while the activation tile is fetched one stage ahead.
+    static constexpr int NA = NA_, NW = NW_;
+    static constexpr bool ASYM = NA_ > 0;
     static constexpr bool DEEP = DEEP_;
     static constexpr int NBUF = NBUF_;                        // LDS ring depth of the direct-to-LDS (glds) pipeline
     // ILV: the fragment reads of macro step s+1 are issued one per gap between the MFMAs of step s instead of as one burst before
@@ -48,13 +54,14 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, 
     static constexpr int SH = ROWS_PER_BANKROW == 2 ? 1 : 2;
     static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     static constexpr int A_LOADS = BM * CH / (THREADS / KG), W_LOADS = BN * CH / (THREADS / KG);
-    static constexpr int LDS_BYTES = KG * NBUF * STAGE_BYTES;
+    static constexpr int LDS_BYTES = NA_ > 0 ? (NA_ * BM + NW_ * BN) * ROWB : KG * NBUF * STAGE_BYTES;
     static constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;   // 32x32 accumulator tiles per wave
     static_assert(BM / WM % 32 == 0 && BN / WN % 64 == 0, "wave tile: rows a multiple of 32, columns a multiple of 64 ([gate 32 | up 32] blocks for SwiGLU)");
     static_assert(BM * CH % (THREADS / KG) == 0 && BN * CH % (THREADS / KG) == 0, "staging must divide evenly");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
+using Cfg256A = TileCfg<256, 128, 4, 2, 128, true, 3, false, 1, 2, 5>;   // the same tile with asymmetric rings: 2 x 32 KB activation + 5 x 16 KB weight buffers (144 KB)
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
 using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
@@ -322,19 +329,38 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     const int n = max(st_end - st_begin, 0);
 
     // per-lane source pointers (at K stage 0) and wave-uniform LDS offsets of this wave's 1-KiB blocks
-    const char* src[PER_WAVE];
-    int cj[PER_WAVE], loff[PER_WAVE];
+    constexpr bool ASYM = C::ASYM;
+    static_assert(!ASYM || (KG == 1 && WAVES % 2 == 0 && BLK_W % (WAVES / 2) == 0 && BLK_A % (WAVES / 2) == 0), "asymmetric rings: half the waves per operand");
+    constexpr int PW_W = ASYM ? BLK_W / (WAVES / 2) : 0, PW_A = ASYM ? BLK_A / (WAVES / 2) : 0;      // pieces per stage of a weight / activation loader wave
+    constexpr int NSRC = ASYM ? (PW_A > PW_W ? PW_A : PW_W) : PER_WAVE;
+    constexpr int A_STAGE = C::BM * C::ROWB, W_STAGE = C::BN * C::ROWB;
+    const bool w_wave = ASYM && wave < WAVES / 2;                 // (wave-uniform)
+    const char* src[NSRC];
+    int cj[NSRC], loff[NSRC];
+    if constexpr (ASYM) {
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-        const int b = wave + WAVES * j;
-        const bool isA = b < BLK_A;
-        const int blk = isA ? b : b - BLK_A;
-        const int row = blk * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
-        cj[j] = c;
-        loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
-        if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
-        else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
+        for (int j = 0; j < NSRC; ++j) {
+            const int blk = (w_wave ? wave : wave - WAVES / 2) + (WAVES / 2) * j;
+            const int row = blk * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
+            cj[j] = c;
+            loff[j] = blk * 1024;
+            if (w_wave) src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;      // (j < PW_W used)
+            else src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int b = wave + WAVES * j;
+            const bool isA = b < BLK_A;
+            const int blk = isA ? b : b - BLK_A;
+            const int row = blk * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
+            cj[j] = c;
+            loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
+            if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
+            else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
+        }
     }
     auto issue = [&](int st, int buf) {
         char* base = ring + buf * C::STAGE_BYTES;
@@ -356,6 +382,41 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             // 6.80 -> 6.63 ms); the activation panel, re-read by every workgroup, stays cached
             if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
             else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+        }
+    };
+    // asymmetric rings: one operand's pieces of stage `st` into buffer `buf` of that operand's ring (weights non-temporal when NTW)
+    auto issue_w = [&](int st, int buf) {
+        char* base = smem + C::NA * A_STAGE + buf * W_STAGE;
+        if ((st + 1) * C::CH <= kchunks) {          // full stage: no per-lane source select in front of the DMA instructions
+#pragma unroll
+            for (int j = 0; j < PW_W; ++j) {
+                const char* g = src[j] + (size_t)st * C::ROWB;
+                if (NTW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
+                else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < PW_W; ++j) {
+            const char* g = src[j] + (size_t)st * C::ROWB;
+            if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
+            if (NTW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+        }
+    };
+    auto issue_a = [&](int st, int buf) {
+        char* base = smem + buf * A_STAGE;
+        if ((st + 1) * C::CH <= kchunks) {
+#pragma unroll
+            for (int j = 0; j < PW_A; ++j)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[j] + (size_t)st * C::ROWB), (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < PW_A; ++j) {
+            const char* g = src[j] + (size_t)st * C::ROWB;
+            if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
         }
     };
 
@@ -385,16 +446,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int rw_ = wc * WCOLS + j * 32 + r32;
-            offW[s][j] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
+            offW[s][j] = lds0 + (ASYM ? C::NA * A_STAGE : C::BM * C::ROWB) + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
         }
     }
     // fragments double-buffered by macro step: the reads of step s+1 are in flight under the MFMAs of step s
     u32x4 fa[2][MI], fb[2][NJ];
-    auto read_step = [&](int s, unsigned bo) {
+    // bo / bow: byte offset of the stage buffer inside the activation / weight ring (one shared ring: bow == bo)
+    auto read_step = [&](int s, unsigned bo, unsigned bow) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
+        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bow));
     };
     auto wait_step = [&](int k, bool more) {          // step in buffer k landed (`more`: the next step's RD reads stay in flight)
         if constexpr (MI == 4 && NJ == 4) {
@@ -412,19 +474,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
     // one fragment read of step s (A fragments first, then W)
-    auto read_one = [&](int s, int q, unsigned bo) {
+    auto read_one = [&](int s, int q, unsigned bo, unsigned bow) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             if (q == i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
+            if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bow));
     };
     // after_first_reads: the DMA issue of a later stage, placed behind the first fragment reads of this one so that its address arithmetic
     // (8 loads x ~8 VALU + the m0 set-up per wave, all waves at once right after the barrier) runs under their LDS latency
-    auto compute = [&](int buf, auto&& after_first_reads) {
-        const unsigned bo = buf * C::STAGE_BYTES;
-        read_step(0, bo);
+    auto compute = [&](unsigned bo, unsigned bow, auto&& after_first_reads) {
+        read_step(0, bo, bow);
         after_first_reads();
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
@@ -438,15 +499,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                     for (int j = 0; j < NJ; ++j) {
                         const u32x4 a4 = fa[s & 1][i], b4 = fb[s & 1][j];
                         mma_chunk<TA>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
-                        if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo);
+                        if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo, bow);
                         ++q;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 if (s + 1 < STEPS)
-                    for (; q < RD; ++q) read_one(s + 1, q, bo);
+                    for (; q < RD; ++q) read_one(s + 1, q, bo, bow);
                 continue;
             }
-            if (s + 1 < STEPS) read_step(s + 1, bo);
+            if (s + 1 < STEPS) read_step(s + 1, bo, bow);
             wait_step(s & 1, s + 1 < STEPS);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -459,6 +520,40 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
 
+    if constexpr (ASYM) {
+        // Weight-loader waves keep DW stages in flight, activation-loader waves one; each wave's counted vmcnt sees only its own operand.
+        // Stage i may be read after: every weight wave has waited for its pieces of W(i), every activation wave for its pieces of A(i),
+        // and the barrier.  A buffer is refilled one iteration after its last read (the barrier in between), as in the shared ring.
+        constexpr int DW = C::NW - 1;
+        static_assert(C::NA == 2 && DW >= 1 && DW <= 4, "activation tile one stage ahead; 1..4 weight stages in flight");
+        if (w_wave) {
+#pragma unroll
+            for (int d = 0; d < DW; ++d)
+                if (d < n) issue_w(st_begin + d, d);
+        } else if (n > 0) {
+            issue_a(st_begin, 0);
+        }
+        int bw = 0, bwn = DW % C::NW, ba = 0;
+        for (int i = 0; i < n; ++i) {
+            if (w_wave) {
+                const int rem = min(DW - 1, n - 1 - i);            // weight stages that may stay in flight behind stage i
+                if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW_W) : "memory");
+                else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW_W) : "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PW_W) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            compute(ba * A_STAGE, bw * W_STAGE, [&]() {
+                if (w_wave) { if (i + DW < n) issue_w(st_begin + i + DW, bwn); }
+                else if (i + 1 < n) issue_a(st_begin + i + 1, ba ^ 1);
+            });
+            ba ^= 1;
+            bw = bw + 1 == C::NW ? 0 : bw + 1;
+            bwn = bwn + 1 == C::NW ? 0 : bwn + 1;
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) issue(st_begin + d, d);
@@ -468,9 +563,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (KG > 1 && i >= n) continue;               // a K-group with one stage less keeps the barrier count of the others
-        compute(buf, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
+        compute(buf * C::STAGE_BYTES, buf * C::STAGE_BYTES, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
+    }
     }
     if constexpr (KG > 1) {
         // Exchange between the two K-groups: group g finishes accumulator rows i with i / (MI / KG) == g, so it hands the OTHER rows to its
@@ -901,11 +997,15 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         }
     }
     constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value;      // the single-row-tile configurations
+    // single-row-tile 256x128 products take the asymmetric-ring form of the tile (force_cfg | 0x4000: the shared 3-deep ring, for tests / A-B)
+    using CN = typename std::conditional<std::is_same<C, Cfg256>::value, Cfg256A, C>::type;
+    const bool asym = std::is_same<C, Cfg256>::value && !(a.force_cfg & 0x4000);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
             if constexpr (HAS_NTW) {
                 if (a.nt_w) {
-                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+                    if (asym) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CN, SPLITK, fp8_t, true>), dim3(wgs), dim3(CN::THREADS), CN::LDS_BYTES, s, a);
+                    else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
                     return;
                 }
             }
@@ -915,7 +1015,8 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
     }
     if constexpr (HAS_NTW) {
         if (a.nt_w) {
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+            if (asym) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CN, SPLITK, T, true>), dim3(wgs), dim3(CN::THREADS), CN::LDS_BYTES, s, a);
+            else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
             return;
         }
     }
@@ -1112,6 +1213,8 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, false, T, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, true, T, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
@@ -1127,6 +1230,8 @@ template <typename T, int EPI> static void gemm_attr() {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, false, fp8_t, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
+        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, true, fp8_t, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);

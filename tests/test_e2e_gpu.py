@@ -1092,7 +1092,7 @@ def test_ragged_scheduler_true_width_vs_oracle():
     m.load_synthetic(SEED)
     m.model.num_history = sc["num_history"]
     proc = m.get_vision_tower().image_processor
-    lengths = lambda e, t: 2 if (e + t) % 2 == 0 else 4
+    lengths = lambda e, t: (2, 2, 4)[(e + t) % 3]                  # env steps until the env's next turn: every 8th step (the window) is a turn step
     agents = []
     for e in range(N):
         enc = SyntheticPromptEncoder(cfg, seed=7 + 31 * e, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
