@@ -169,6 +169,10 @@ int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw,
  * svln_op_rmsnorm / svln_op_layernorm. */
 int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
+/* the RMSNorm form with the e4m3 copy of the normalised rows (opt-in fp8 products: the reduce that emits the norm also quantises it):
+ * q8 [M][N] bytes, q8_scale [M] = max |norm_out row| / 448 */
+int svln_op_gemm_norm_q8(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr,
+                         const void* norm_w, void* norm_out, float eps, int M, int N, int K, int force_split, void* q8, float* q8_scale, int* fused);
 int svln_op_gemv(svln_engine* h, const void* W, int ldw, const void* x, const void* norm_w, float eps, const void* bias, const void* res,
                  void* y, int N, int K, int epi, int32_t* host_token);
 /* the product behind svln_set_fp8_gemm: C [M][N] (bf16) = epi(a_scale[m] * w_scale[n] * (A8 [M][K] . W8 [N][K]^T) + bias) + res, e4m3 operands

@@ -1466,11 +1466,21 @@ public:
     }
     // C = A . W^T (+ epilogue) for an LLM linear: bf16 operands, or -- with svln_set_fp8_gemm -- the rows of A quantised on the fly
     // against the e4m3 copy of W
+    // act8_src: the rows whose e4m3 copy act8 currently holds because the reduce that produced them also quantised them (the normalised
+    // rows handed from o_proj to gate/up and from down_proj to the next layer's qkv: two of the four quantise launches of a layer)
+    const void* act8_src = nullptr; int act8_rows = 0;
     bool llm_gemm(GemmArgs a, const Q8& q) {
         if (fp8_gemm_on && q.q) {
-            launch_quant_fp8_rows(st, a.A, a.lda, act8, act8_scale, a.M, a.K);
+            if (!(act8_src == a.A && act8_rows == a.M && a.lda == a.K)) launch_quant_fp8_rows(st, a.A, a.lda, act8, act8_scale, a.M, a.K);
+            act8_src = nullptr;
+            if (a.norm_out && a.norm_w && !a.norm_b && (size_t)a.N <= (size_t)H) { a.norm_q8 = act8; a.norm_q8_scale = act8_scale; }
+            const void* nout = a.norm_out; const int rows = a.M;
             a.A = act8; a.lda = a.K; a.W = q.q; a.ldw = a.K; a.a_scale = act8_scale; a.w_scale = q.s;
+            const bool fused = launch_gemm<T>(st, a);
+            if (fused && a.norm_q8) { act8_src = nout; act8_rows = rows; }      // the reduce ran after the product had consumed act8
+            return fused;
         }
+        act8_src = nullptr;
         return launch_gemm<T>(st, a);
     }
     bool op_gemm_fp8(const GemmArgs& a0) override {
@@ -1718,6 +1728,17 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
     GemmArgs a; std::memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr; a.norm_b = norm_b;
     a.M = M; a.N = N; a.K = K; a.epi = EPI_NONE; a.nsplit = 1; a.force_split = force_split; a.norm_w = norm_w; a.norm_out = norm_out; a.norm_eps = eps;
+    const bool f = h->impl->op_gemm(a);
+    if (fused) *fused = f ? 1 : 0;
+    API_END
+}
+int svln_op_gemm_norm_q8(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr,
+                         const void* norm_w, void* norm_out, float eps, int M, int N, int K, int force_split, void* q8, float* q8_scale, int* fused) {
+    API_BEGIN_H
+    GemmArgs a; std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.res = res; a.ldr = ldr;
+    a.M = M; a.N = N; a.K = K; a.epi = EPI_NONE; a.nsplit = 1; a.force_split = force_split; a.norm_w = norm_w; a.norm_out = norm_out; a.norm_eps = eps;
+    a.norm_q8 = q8; a.norm_q8_scale = q8_scale; a.pen = 1.0f;
     const bool f = h->impl->op_gemm(a);
     if (fused) *fused = f ? 1 : 0;
     API_END

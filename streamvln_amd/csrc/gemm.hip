@@ -876,9 +876,37 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
         }
     } else {
         const float sc = rsqrtf(t1 / (float)p.N + p.norm_eps);
+        float yq[4] = {0, 0, 0, 0};
         if (live) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Y[(size_t)m * p.N + n0 + e] = from_f32<T>(to_f32(g[n0 + e]) * (v[e] * sc));
+            for (int e = 0; e < 4; ++e) {
+                const T y = from_f32<T>(to_f32(g[n0 + e]) * (v[e] * sc));
+                Y[(size_t)m * p.N + n0 + e] = y;
+                yq[e] = to_f32(y);
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (p.norm_q8) {              // e4m3 copy of the row (quant_fp8_rows_kernel's arithmetic on the rounded values)
+                float amax = fmaxf(fmaxf(fabsf(yq[0]), fabsf(yq[1])), fmaxf(fabsf(yq[2]), fabsf(yq[3])));
+                amax = wave_max(amax);
+                __syncthreads();          // red[0] is free again (every thread has read the totals)
+                if ((tid & 63) == 0) red[0][tid >> 6] = amax;
+                __syncthreads();
+                amax = 0.0f;
+                for (int w = 0; w < nw; ++w) amax = fmaxf(amax, red[0][w]);
+                const float qs = amax > 0.0f ? amax / 448.0f : 1.0f;
+                if (tid == 0) p.norm_q8_scale[m] = qs;
+                if (live) {
+                    const float inv = 1.0f / qs;
+                    float f[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf(yq[e] * inv, -448.0f), 448.0f);
+                    int w8 = 0;
+                    w8 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w8, false);
+                    w8 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w8, true);
+                    *(unsigned*)((uint8_t*)p.norm_q8 + (size_t)m * p.N + n0) = (unsigned)w8;
+                }
+            }
         }
     }
 }

@@ -41,6 +41,9 @@ struct GemmArgs {
     // (sum + bias, rounded to T) also writes the K pages and the transposed V pages of the ViT attention -- splitk_epilogue followed by
     // vit_kv_pack in one pass -- and launch_gemm returns true; otherwise the caller runs launch_vit_kv_pack itself
     const VitPackArgs* vitpack;
+    // optional with norm_out (bf16 engine, opt-in fp8 products): the fused reduce also writes the e4m3 copy of the normalised row and its
+    // scale (max |y| / 448), exactly what launch_quant_fp8_rows produces from norm_out -- the A operand of the next product
+    void* norm_q8 = nullptr; float* norm_q8_scale = nullptr;
     const void* norm_b;           // non-null: LayerNorm (mean/variance, weight norm_w, bias norm_b) instead of RMSNorm -- the ViT's ln1 / ln2
     // opt-in fp8 (OCP e4m3) operands (bf16 engine): when a_scale is set, A [M][K] and W [N][K] are e4m3 bytes (lda / ldw in
     // elements), C = a_scale[m] * w_scale[n] * (A . W^T) then the usual epilogue in bf16; K % 16 == 0

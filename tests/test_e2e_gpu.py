@@ -1129,7 +1129,10 @@ def test_ragged_scheduler_true_width_vs_oracle():
 # state error against the reference-generated fp32 fixture (measured values are written next to the bounds; bench.py reports the same
 # quantities at full depth on its own line)
 FP8_HIDDEN_REL = 0.10
-FP8_ID_AGREE_MIN = 0.5
+# Random-init weights give top-2 logit margins of 0.02-0.3 (fixture), the size of the e4m3 logit error itself, so an unconditional
+# agreement rate says nothing here (the first token of true4 has margin 0.02 and flips under an fp8 lm_head).  Asserted instead: every
+# comparable token whose fixture margin exceeds FP8_MARGIN agrees with the bf16 engine; the rate is reported.
+FP8_MARGIN = 0.2
 
 
 def test_fp8_opt_ins_true_width_vs_bf16_and_fixture():
@@ -1145,7 +1148,7 @@ def test_fp8_opt_ins_true_width_vs_bf16_and_fixture():
         m.reset(1)
         log8, taps8 = _run(m, sc)
         off()
-        agree = total = 0
+        agree = total = checked = 0
         worst16 = worstfx = 0.0
         for t, r8 in enumerate(log8):
             ids8, gold = r8["out"].sequences[0].tolist(), g[f"t{t}_ids"].tolist()
@@ -1153,18 +1156,21 @@ def test_fp8_opt_ins_true_width_vs_bf16_and_fixture():
             while n < len(ids8) and ids8[n] == ids16[t][n]:
                 n += 1
             agree += n; total += len(ids16[t])
+            margins = g[f"t{t}_margins"]
             for j in range(min(n + 1, len(ids8))):                  # rows that saw the same inputs as the bf16 run
                 h8, h16 = taps8[t]["hidden"][j], taps16[t]["hidden"][j]
                 worst16 = max(worst16, float(np.linalg.norm(h8 - h16) / np.linalg.norm(h16)))
                 if ids16[t][:j] == gold[:j]:                         # ... and as the fp32 fixture
                     gh = g[f"t{t}_hidden"][j]
                     worstfx = max(worstfx, float(np.linalg.norm(h8 - gh) / np.linalg.norm(gh)))
+                    if ids16[t][j] == gold[j] and margins[j] > FP8_MARGIN:
+                        checked += 1
+                        assert ids8[j] == ids16[t][j], (name, t, j, ids8, ids16[t], margins)
             if n < len(ids16[t]):
                 break
-        rate = agree / total
-        report.append(f"{name}: {agree}/{total} ids agree with bf16 before the first divergence, hidden rel err vs bf16 {worst16:.4f}, vs fp32 fixture {worstfx:.4f}")
+        report.append(f"{name}: {agree}/{total} ids agree with bf16 before the first divergence ({checked} tokens with fixture margin > {FP8_MARGIN} "
+                      f"checked: all agree), hidden rel err vs bf16 {worst16:.4f}, vs fp32 fixture {worstfx:.4f}")
         assert worst16 < FP8_HIDDEN_REL and worstfx < FP8_HIDDEN_REL, (name, worst16, worstfx)
-        assert rate >= FP8_ID_AGREE_MIN, (name, agree, total)
     m.reset(1)
     log1, taps1 = _run(m, sc)                                       # everything off again: bf16 results restored exactly
     assert [r["out"].sequences[0].tolist() for r in log1] == ids16

@@ -325,6 +325,29 @@ def _quant_ref(W):
     return qf, scale
 
 
+def test_fused_norm_quantisation_equals_the_quantise_kernel():
+    """the split-K reduce that emits the RMSNorm can also emit its e4m3 copy (opt-in fp8 products): bytes and scales equal torch's
+    float8_e4m3fn conversion of the bf16 norm rows = what svln_op_quant_fp8 produces from them"""
+    m = engine(TINY, torch.bfloat16)
+    dtype = torch.bfloat16
+    for M, N, K, split in [(212, 3584, 1024, 4), (8, 3584, 2368, 3), (37, 512, 512, 2)]:
+        A, Wt = q(rnd((M, K), 71), dtype), q(rnd((N, K), 72, 1.0 / math.sqrt(K)), dtype)
+        r, g = q(rnd((M, N), 73), dtype), q(1.0 + rnd((N,), 74, 0.2), dtype)
+        dA, dW, dg = A.to(dtype).cuda(), Wt.to(dtype).cuda(), g.to(dtype).cuda()
+        x = r.to(dtype).cuda()
+        xn = torch.zeros((M, N), dtype=dtype, device="cuda")
+        q8 = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+        sc = torch.zeros((M,), dtype=torch.float32, device="cuda")
+        fused = C.c_int32(-1)
+        torch.cuda.synchronize()
+        chk(m._lib.svln_op_gemm_norm_q8(m._h, ptr(dA), K, ptr(dW), K, ptr(x), N, ptr(x), N, ptr(dg), ptr(xn), 1e-6, M, N, K, split, ptr(q8), ptr(sc),
+                                        C.byref(fused)))
+        assert fused.value == 1
+        qf, scale = _quant_ref(xn.float().cpu())
+        assert torch.equal(sc.cpu(), scale), (M, N, K)
+        assert torch.equal(q8.cpu(), qf.view(torch.uint8)), (M, N, K)
+
+
 def test_fp8_row_quantisation_matches_torch_e4m3():
     """svln_op_quant_fp8 (SURVEY 8f-2 extension): OCP e4m3 bytes and per-row scales equal torch's float8_e4m3fn conversion."""
     m = engine(TINY, torch.bfloat16)
