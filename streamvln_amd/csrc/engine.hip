@@ -145,6 +145,7 @@ public:
     // llm workspaces
     T *x, *xn, *qkv, *attn, *hbuf, *hid_tap, *head_xn;
     float* gemm_ws = nullptr; size_t gemm_ws_elems = 0; void* zero_line = nullptr;
+    int gemm_force = 0;          // experiment knob (tools/ab_lib.sh): SVLN_GEMM_FORCE is OR-ed into force_cfg of every engine-issued product
     float* inv_freq; float* rope_tab;
     float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
@@ -208,6 +209,7 @@ public:
     Engine(const svln_config& cfg, int dev) : c(cfg), device(dev) {
         DeviceGuard guard(dev);
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if (const char* gf = getenv("SVLN_GEMM_FORCE")) gemm_force = (int)strtol(gf, nullptr, 0);
         Hv = c.v_hidden; Iv = c.v_inter; vheads = c.v_heads; vhd = Hv / vheads; side = c.v_image / c.v_patch; S = side * side;
         kp = ((3 * c.v_patch * c.v_patch + 7) / 8) * 8;
         oside = (side + 1) / 2; otok = oside * oside;
@@ -466,7 +468,7 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
+        a.zeros = zero_line; a.force_cfg = gemm_force; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
         a.a_scale = nullptr; a.w_scale = nullptr; a.rope = nullptr; a.vitpack = nullptr; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {

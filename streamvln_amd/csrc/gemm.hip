@@ -404,16 +404,23 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
         }
     };
+    // activation pieces: 8-row blocks that lie wholly past row M are not fetched at all (at M = 212, 5 of the 32 blocks of the 256-row tile):
+    // their LDS rows keep stale bytes, which only feed accumulator rows that are never stored.  The activation waves wait with vmcnt(0), so
+    // a wave-dependent piece count needs no change of the wait.
+    const int a_blk0 = wave - WAVES / 2, a_rows = p.M - row0;
     auto issue_a = [&](int st, int buf) {
         char* base = smem + buf * A_STAGE;
         if ((st + 1) * C::CH <= kchunks) {
 #pragma unroll
-            for (int j = 0; j < PW_A; ++j)
+            for (int j = 0; j < PW_A; ++j) {
+                if ((a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;       // (wave-uniform)
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[j] + (size_t)st * C::ROWB), (lds_ptr_t)(base + loff[j]), 16, 0, 0);
+            }
             return;
         }
 #pragma unroll
         for (int j = 0; j < PW_A; ++j) {
+            if ((a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;
             const char* g = src[j] + (size_t)st * C::ROWB;
             if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
