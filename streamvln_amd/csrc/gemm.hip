@@ -61,7 +61,7 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, 
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
-using Cfg256A = TileCfg<256, 128, 4, 2, 128, true, 3, false, 1, 2, 5>;   // the same tile with asymmetric rings: 2 x 32 KB activation + 5 x 16 KB weight buffers (144 KB)
+using Cfg256A = TileCfg<256, 128, 4, 2, 128, true, 3, false, 1, 3, 4>;   // the same tile with asymmetric rings: 2 x 32 KB activation + 5 x 16 KB weight buffers (144 KB)
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
 using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
@@ -282,7 +282,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // A template parameter, not a run-time flag: a branch around the DMA issue of the large-tile kernels cost the window-restart prefill 2.5 ms.
 // VP: the fused K / V^T packing tail of the SigLIP QKV product (a template parameter: as a run-time flag its tests sat in the store loop of
 // every plain epilogue and cost the window-restart turn 2.8 ms).
-template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false>
+// TW: the weight tile comes from the stage-major tiled copy p.Wt (GemmArgs::Wt): piece b of stage st of column tile bn is the contiguous
+// KiB at ((bn * stages + st) * BN * 128 B) + b * 1 KiB, lane l its chunk l -- no row stride, no source swizzle (the copy is pre-swizzled).
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false, bool TW = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
@@ -359,16 +361,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             cj[j] = c;
             loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
             if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
+            else if (TW) src[j] = (const char*)p.Wt + (size_t)bn * stages_total * W_STAGE + (size_t)blk * 1024 + lane * 16;
             else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
         }
     }
+    static_assert(!TW || (NTW && !ASYM && sizeof(TA) == sizeof(T)), "tiled weights: the single-row-tile kernels, engine operand type");
     auto issue = [&](int st, int buf) {
         char* base = ring + buf * C::STAGE_BYTES;
         const bool full = (st + 1) * C::CH <= kchunks;
         if (full) {                       // every stage but a ragged last one: no per-lane source select in front of the DMA instructions
 #pragma unroll
             for (int j = 0; j < PER_WAVE; ++j) {
-                const char* g = src[j] + (size_t)st * C::ROWB;
+                const char* g = src[j] + (size_t)st * ((TW && j >= BLK_A / WAVES) ? W_STAGE : C::ROWB);      // (tiled weights: K is whole stages)
                 if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
                 else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
             }
@@ -413,14 +417,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         if ((st + 1) * C::CH <= kchunks) {
 #pragma unroll
             for (int j = 0; j < PW_A; ++j) {
-                if ((a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;       // (wave-uniform)
+                if (C::NA == 2 && (a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;       // (wave-uniform; only with a full drain per stage: the counted wait assumes PW_A pieces)
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[j] + (size_t)st * C::ROWB), (lds_ptr_t)(base + loff[j]), 16, 0, 0);
             }
             return;
         }
 #pragma unroll
         for (int j = 0; j < PW_A; ++j) {
-            if ((a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;
+            if (C::NA == 2 && (a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;
             const char* g = src[j] + (size_t)st * C::ROWB;
             if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
@@ -531,16 +535,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         // Weight-loader waves keep DW stages in flight, activation-loader waves one; each wave's counted vmcnt sees only its own operand.
         // Stage i may be read after: every weight wave has waited for its pieces of W(i), every activation wave for its pieces of A(i),
         // and the barrier.  A buffer is refilled one iteration after its last read (the barrier in between), as in the shared ring.
-        constexpr int DW = C::NW - 1;
-        static_assert(C::NA == 2 && DW >= 1 && DW <= 4, "activation tile one stage ahead; 1..4 weight stages in flight");
+        constexpr int DW = C::NW - 1, DA = C::NA - 1;
+        static_assert(DA >= 1 && DA <= 2 && DW >= 1 && DW <= 4, "1..2 activation stages, 1..4 weight stages in flight");
         if (w_wave) {
 #pragma unroll
             for (int d = 0; d < DW; ++d)
                 if (d < n) issue_w(st_begin + d, d);
-        } else if (n > 0) {
-            issue_a(st_begin, 0);
+        } else {
+#pragma unroll
+            for (int d = 0; d < DA; ++d)
+                if (d < n) issue_a(st_begin + d, d);
         }
-        int bw = 0, bwn = DW % C::NW, ba = 0;
+        int bw = 0, bwn = DW % C::NW, ba = 0, ban = DA % C::NA;
         for (int i = 0; i < n; ++i) {
             if (w_wave) {
                 const int rem = min(DW - 1, n - 1 - i);            // weight stages that may stay in flight behind stage i
@@ -549,14 +555,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                 else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PW_W) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (DA > 1 && min(DA - 1, n - 1 - i) >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW_A) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
             compute(ba * A_STAGE, bw * W_STAGE, [&]() {
                 if (w_wave) { if (i + DW < n) issue_w(st_begin + i + DW, bwn); }
-                else if (i + 1 < n) issue_a(st_begin + i + 1, ba ^ 1);
+                else if (i + DA < n) issue_a(st_begin + i + DA, ban);
             });
-            ba ^= 1;
+            ba = ba + 1 == C::NA ? 0 : ba + 1;
+            ban = ban + 1 == C::NA ? 0 : ban + 1;
             bw = bw + 1 == C::NW ? 0 : bw + 1;
             bwn = bwn + 1 == C::NW ? 0 : bwn + 1;
         }
@@ -1032,9 +1040,10 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         }
     }
     constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value;      // the single-row-tile configurations
-    // single-row-tile 256x128 products take the asymmetric-ring form of the tile (force_cfg | 0x4000: the shared 3-deep ring, for tests / A-B)
+    // force_cfg | 0x4000: the asymmetric-ring form of the 256x128 tile (measured no faster than the shared 3-deep ring: DESIGN.md 4.1; kept
+    // reachable for tests / A-B)
     using CN = typename std::conditional<std::is_same<C, Cfg256>::value, Cfg256A, C>::type;
-    const bool asym = std::is_same<C, Cfg256>::value && !(a.force_cfg & 0x4000);
+    const bool asym = std::is_same<C, Cfg256>::value && (a.force_cfg & 0x4000);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
             if constexpr (HAS_NTW) {
@@ -1049,6 +1058,10 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         }
     }
     if constexpr (HAS_NTW) {
+        if (a.nt_w && a.Wt && !asym) {      // stage-major weight copy (launch_epi keeps Wt only for shapes it is valid for)
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true, false, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+            return;
+        }
         if (a.nt_w) {
             if (asym) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CN, SPLITK, T, true>), dim3(wgs), dim3(CN::THREADS), CN::LDS_BYTES, s, a);
             else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
@@ -1090,6 +1103,8 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return false;
     a.vp_on = 0;
     a.nt_w = a.M <= 256 ? 1 : 0;          // the heuristics below give such products ONE row tile (256x128 or 32x128 tiles)
+    if (!(a.nt_w && !a.a_scale && a.zeros && a.N % 128 == 0 && a.K % (8 * Elt<T>::PER_CHUNK) == 0 && !(a.force_cfg & 0x2000))) a.Wt = nullptr;
+    if (a.force_cfg & 0x8000) a.Wt = nullptr;      // tests / A-B: row-major weights only
     const int EPC = a.a_scale ? 16 : Elt<T>::PER_CHUNK;      // 16-byte chunks of K: e4m3 operands hold 16 values per chunk
     a.tile_base = 0;
     if (a.force_split > 1) {      // a forced split obeys the same workspace / shape limits as the heuristic ones
@@ -1217,12 +1232,39 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
 
 }  // namespace
 
+namespace {
+// row-major W -> stage-major tiled copy (GemmArgs::Wt).  One thread = one 16-byte chunk of the image: chunk l of piece b of stage st of
+// column tile t holds W[t*128 + b*8 + l/8][(st*8 + ((l%8) ^ swizzle(row))) chunks], the swizzle of the 128-byte-row LDS tiles (swz<>).
+template <typename T>
+__global__ __launch_bounds__(256) void tile_pack_kernel(const T* W, int ldw, int tiles_n, int stages, T* Wt) {
+    constexpr int EPC = Elt<T>::PER_CHUNK;
+    const size_t total = (size_t)tiles_n * stages * 1024;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int within = (int)(id & 1023), st = (int)((id >> 10) % stages), t = (int)((id >> 10) / stages);
+        const int b = within >> 6, l = within & 63, row = b * 8 + (l >> 3);
+        const int c = (l & 7) ^ ((row >> Cfg256::SH) & 7);
+        *(uint4*)(Wt + id * EPC) = *(const uint4*)(W + (size_t)(t * 128 + row) * ldw + (size_t)(st * 8 + c) * EPC);
+    }
+}
+}  // namespace
+template <typename T> void launch_tile_pack(hipStream_t s, const void* W, int ldw, int N, int K, void* Wt) {
+    const int tiles_n = N / 128, stages = K / (8 * Elt<T>::PER_CHUNK);
+    const size_t total = (size_t)tiles_n * stages * 1024;
+    int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL((tile_pack_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)W, ldw, tiles_n, stages, (T*)Wt);
+}
+template void launch_tile_pack<bf16>(hipStream_t, const void*, int, int, int, void*);
+template void launch_tile_pack<float>(hipStream_t, const void*, int, int, int, void*);
+
 // lm_head of <= 32 rows (envs decoded together) with the arg-max in the epilogue: one pass of 32x128 tiles over the vocabulary, the weight
 // tile staged non-temporally, no C.  Returns the number of column tiles (= partials per row).
 template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a) {
     a.nt_w = 1; a.tile_base = 0; a.nsplit = 1; a.vp_on = 0;
     a.launch_tiles = (a.N + 127) / 128;
-    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
+    if (a.Wt && a.N % 128 == 0 && a.K % (8 * Elt<T>::PER_CHUNK) == 0 && !(a.force_cfg & 0x8000))
+        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true, false, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
     return a.launch_tiles;
 }
 template int launch_gemm_argmax<bf16>(hipStream_t, GemmArgs);
@@ -1248,6 +1290,10 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true, false, true>, Cfg256::LDS_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true, false, true>, Cfg256::LDS_BYTES, Cfg256::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true, false, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true, false, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, false, T, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, true, T, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
@@ -1279,6 +1325,7 @@ template <typename T, int EPI> static void gemm_attr() {
 }
 template <typename T> static void gemm_argmax_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true, false, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
 }
 void gemm_init_attrs() {
     gemm_argmax_attr<bf16>(); gemm_argmax_attr<float>();
