@@ -169,10 +169,6 @@ int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw,
  * svln_op_rmsnorm / svln_op_layernorm. */
 int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
                       const void* norm_w, const void* norm_b, void* norm_out, float eps, int M, int N, int K, int force_split, int* fused);
-/* svln_op_gemm for M <= 256 with W read from its stage-major tiled copy (built from the row-major W for the call): the form in which the
- * engine streams the LLM's weights in the steady prefill and the batched decode step (N % 128 == 0, K a whole number of 128-byte stages) */
-int svln_op_gemm_tiled(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
-                       int M, int N, int K, int epi, int force_split);
 /* the RMSNorm form with the e4m3 copy of the normalised rows (opt-in fp8 products: the reduce that emits the norm also quantises it):
  * q8 [M][N] bytes, q8_scale [M] = max |norm_out row| / 448 */
 int svln_op_gemm_norm_q8(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr,

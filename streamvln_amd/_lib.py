@@ -76,7 +76,6 @@ SIGNATURES = {
     "svln_feature_cache_stats": (_I, [_P, _PI64, _PI64]),
     "svln_op_gemm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemm_norm": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _PI32]),
-    "svln_op_gemm_tiled": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I]),
     "svln_op_gemm_norm_q8": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _PI32]),
     "svln_op_gemv": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _PI32]),
     "svln_op_gemm_fp8": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I]),

@@ -103,7 +103,6 @@ struct EngineBase {
     virtual void set_feature_cache(int cap) = 0;
     virtual void feature_cache_stats(int64_t* hits, int64_t* misses) = 0;
     virtual bool op_gemm(const GemmArgs& a) = 0;
-    virtual bool op_gemm_tiled(const GemmArgs& a) = 0;
     virtual void op_gemv(GemvArgs a, int32_t* host_token) = 0;
     virtual void op_gemv_batched(GemvBatchArgs a, int32_t* host_tokens) = 0;
     virtual void op_quant_fp8(const void* w, int64_t rows, int cols, void* w8, float* scale) = 0;
@@ -131,12 +130,7 @@ public:
 
     struct VLayer { T *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
     struct Q8 { uint8_t* q = nullptr; float* s = nullptr; };      // fp8 (e4m3) copy of a weight matrix + per-row scales (opt-in decode mode)
-    // *_wt: stage-major tiled second copies of the four linears (GemmArgs::Wt; null when the shape does not tile): the weight stream of
-    // the M <= 256 products (steady prefill, batched decode) reads 16 KiB contiguous per stage instead of 128-byte pieces a row apart.
-    // 288 GB of HBM: the extra 13.6 GB (bf16, true size) buy contiguous DRAM bursts.
-    struct LLayer { T *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gu_w, *down_w, *kpool, *vpool; Q8 qkv8, o8, gu8, down8;
-                    T *qkv_wt = nullptr, *o_wt = nullptr, *gu_wt = nullptr, *down_wt = nullptr; };
-    T* lm_head_wt = nullptr; bool tiled_valid = false;
+    struct LLayer { T *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gu_w, *down_w, *kpool, *vpool; Q8 qkv8, o8, gu8, down8; };
     Q8 lm_head8; bool fp8_on = false, fp8_built = false;
     bool fp8_gemm_on = false; uint8_t* act8 = nullptr; float* act8_scale = nullptr;      // opt-in fp8 MFMA products: quantised activation rows
     T *patch_w, *patch_b, *pos_emb, *proj0_w, *proj0_b, *proj2_w, *proj2_b, *embed, *final_norm, *lm_head;
@@ -151,7 +145,6 @@ public:
     // llm workspaces
     T *x, *xn, *qkv, *attn, *hbuf, *hid_tap, *head_xn;
     float* gemm_ws = nullptr; size_t gemm_ws_elems = 0; void* zero_line = nullptr;
-    int gemm_force = 0;          // experiment knob (tools/ab_lib.sh): SVLN_GEMM_FORCE is OR-ed into force_cfg of every engine-issued product
     float* inv_freq; float* rope_tab;
     float* attn_part; size_t attn_part_elems = 0; int nsplit_max, tiles_per_split;
     float* part_val; int* part_idx; int* d_token; float* d_top2;
@@ -211,26 +204,10 @@ public:
     }
 
     int device_id() const override { return device; }
-    static bool tiles(int N, int K) { return N % 128 == 0 && K % (8 * Elt<T>::PER_CHUNK) == 0; }
-    T* tiled_alloc(int N, int K) { return tiles(N, K) ? dalloc<T>((size_t)N * K) : nullptr; }
-    // (re)build the tiled copies from the row-major tensors; called before the LLM runs whenever a tensor has changed since
-    void ensure_tiled() {
-        if (tiled_valid) return;
-        const int qd = nq * 128;
-        for (auto& L : ll) {
-            if (L.qkv_wt) launch_tile_pack<T>(st, L.qkv_w, H, qkv_dim, H, L.qkv_wt);
-            if (L.o_wt) launch_tile_pack<T>(st, L.o_w, qd, H, qd, L.o_wt);
-            if (L.gu_wt) launch_tile_pack<T>(st, L.gu_w, H, 2 * I, H, L.gu_wt);
-            if (L.down_wt) launch_tile_pack<T>(st, L.down_w, I, H, I, L.down_wt);
-        }
-        if (lm_head_wt) launch_tile_pack<T>(st, lm_head, H, V, H, lm_head_wt);
-        tiled_valid = true;
-    }
 
     Engine(const svln_config& cfg, int dev) : c(cfg), device(dev) {
         DeviceGuard guard(dev);
         HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        if (const char* gf = getenv("SVLN_GEMM_FORCE")) gemm_force = (int)strtol(gf, nullptr, 0);
         Hv = c.v_hidden; Iv = c.v_inter; vheads = c.v_heads; vhd = Hv / vheads; side = c.v_image / c.v_patch; S = side * side;
         kp = ((3 * c.v_patch * c.v_patch + 7) / 8) * 8;
         oside = (side + 1) / 2; otok = oside * oside;
@@ -287,7 +264,6 @@ public:
             L.o_w = dalloc<T>((size_t)H * qd); L.gu_w = dalloc<T>((size_t)2 * I * H); L.down_w = dalloc<T>((size_t)H * I);
             L.kpool = dalloc<T>((size_t)pages_total * nkv * PAGE * 128, true);
             L.vpool = dalloc<T>((size_t)pages_total * nkv * 128 * PAGE, true);
-            L.qkv_wt = tiled_alloc(qkv_dim, H); L.o_wt = tiled_alloc(H, qd); L.gu_wt = tiled_alloc(2 * I, H); L.down_wt = tiled_alloc(H, I);
             add_slot(P + "input_layernorm.weight", L.in_norm, H, 1, H);
             add_slot(P + "post_attention_layernorm.weight", L.post_norm, H, 1, H);
             add_linear(P + "self_attn.q_proj", L.qkv_w, L.qkv_b, qd, H);
@@ -299,7 +275,6 @@ public:
             add_linear(P + "mlp.down_proj", L.down_w, nullptr, H, I);
         }
         final_norm = dalloc<T>(H); lm_head = dalloc<T>((size_t)V * H);
-        lm_head_wt = tiled_alloc(V, H);
         add_slot("model.norm.weight", final_norm, H, 1, H);
         add_slot("lm_head.weight", lm_head, H, V, H);
 
@@ -423,7 +398,7 @@ public:
     void synth_tensor(const char* name, uint64_t seed_t, float hw, float base) override {
         Slot& s = slot(name);
         launch_synth<T>(st, s.dst, s.ld, s.rows, s.cols, s.map, seed_t, hw, base);
-        s.filled = true; tiled_valid = false;
+        s.filled = true;
     }
     void set_tensor(const char* name, const void* data, int dtype, int64_t numel, int on_device) override {
         Slot& s = slot(name);
@@ -439,7 +414,7 @@ public:
         launch_convert<T>(st, s.dst, s.ld, s.rows, s.cols, s.map, src, dtype == SVLN_F32);
         HIP_CHECK(hipStreamSynchronize(st));
         if (tmp) HIP_CHECK(hipFree(tmp));
-        s.filled = true; tiled_valid = false;
+        s.filled = true;
     }
     int weights_missing() override {
         int n = 0;
@@ -491,7 +466,7 @@ public:
                        int res_mod, int M, int N, int K, int epi) {
         GemmArgs a; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
         a.res_mod = res_mod; a.M = M; a.N = N; a.K = K; a.epi = epi; a.ws = gemm_ws; a.ws_elems = gemm_ws_elems; a.nsplit = 1;
-        a.zeros = zero_line; a.force_cfg = gemm_force; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
+        a.zeros = zero_line; a.force_cfg = 0; a.force_split = 0; a.norm_w = nullptr; a.norm_out = nullptr; a.norm_eps = 0.0f; a.norm_b = nullptr;
         a.a_scale = nullptr; a.w_scale = nullptr; a.rope = nullptr; a.vitpack = nullptr; return a;
     }
     AttnArgs vit_attn_args(const void* q, int ld, int F, void* out, int o_stride) {
@@ -826,7 +801,7 @@ public:
             r0.nq = nq; r0.nkv = nkv; r0.dyn_pos = nullptr;
             GemmArgs aq = gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE);
             if (segs.size() == 1 && n_dec == 0) { r0.page_table = segs[0].e->d_pages; r0.T = segs[0].Tn; r0.P = segs[0].P; aq.rope = &r0; }
-            const bool roped = llm_gemm(aq, L.qkv8, L.qkv_wt);
+            const bool roped = llm_gemm(aq, L.qkv8);
             if (n_dec > 0) {
                 AttnArgs a = batched_decode_attn_args(L, n_dec);
                 launch_attention<T>(st, a, 128, 1);
@@ -844,14 +819,14 @@ public:
             // the split-K reduce of o_proj / down_proj also emits the following RMSNorm when it can (T <= 256 rows)
             GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE);
             ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
-            if (!llm_gemm(ao, L.o8, L.o_wt)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
+            if (!llm_gemm(ao, L.o8)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
             const bool pp = i == 0 && probe_on && M <= 256 && n_dec == 0 && pprobe_used + 2 <= pprobe_ev.size();
             if (pp) HIP_CHECK(hipEventRecord(pprobe_ev[pprobe_used], st));
-            llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU), L.gu8, L.gu_wt);
+            llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU), L.gu8);
             if (pp) { HIP_CHECK(hipEventRecord(pprobe_ev[pprobe_used + 1], st)); pprobe_used += 2; pprobe_rows += M; }
             GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE);
             if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
-            xn_ready = llm_gemm(ad, L.down8, L.down_wt);
+            xn_ready = llm_gemm(ad, L.down8);
         }
     }
     AttnArgs batched_decode_attn_args(const LLayer& L, int B) {
@@ -995,7 +970,6 @@ public:
         if (B >= batched_mfma_min && K % Elt<T>::PER_CHUNK == 0 && (N + 127) / 128 <= 2048) {
             GemmArgs a = gemm_args(xrows, ldx, W, ldw, nullptr, 0, nullptr, nullptr, 0, 0, B, N, K, EPI_ARGMAX);
             a.part_val = part_val_b; a.part_idx = part_idx_b;
-            if (W == (const void*)lm_head && tiled_valid) a.Wt = lm_head_wt;
             if (pen) { a.pen_flags = pen_flags_b; a.pen_rows = d_pen_rows; a.pen = rep_penalty; }
             const int n = launch_gemm_argmax<T>(st, a);
             launch_argmax_final_batched(st, part_val_b, part_idx_b, n, B, d_tok_b);
@@ -1023,7 +997,7 @@ public:
             const LLayer& L = ll[i];
             // RMSNorm as its own tiny launch in the batched step (amortised over B envs)
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, B, H, c.rms_eps);
-            if (mfma) llm_gemm(gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE), L.qkv8, L.qkv_wt);
+            if (mfma) llm_gemm(gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, B, qkv_dim, H, EPI_NONE), L.qkv8);
             else launch_gemv_batched<T>(st, gemvb_args(L.qkv_w, H, xn, H, nullptr, L.qkv_b, nullptr, 0, qkv, qkv_dim, qkv_dim, H, EPI_NONE, B));
             AttnArgs a = batched_decode_attn_args(L, B);
             launch_attention<T>(st, a, 128, 1);
@@ -1031,11 +1005,11 @@ public:
             if (mfma) {
                 GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, B, H, qd, EPI_NONE);
                 ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
-                if (!llm_gemm(ao, L.o8, L.o_wt)) launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
-                llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, B, 2 * I, H, EPI_SWIGLU), L.gu8, L.gu_wt);
+                if (!llm_gemm(ao, L.o8)) launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
+                llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, B, 2 * I, H, EPI_SWIGLU), L.gu8);
                 GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, B, H, I, EPI_NONE);
                 if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
-                xn_ready = llm_gemm(ad, L.down8, L.down_wt);
+                xn_ready = llm_gemm(ad, L.down8);
             } else {
                 launch_gemv_batched<T>(st, gemvb_args(L.o_w, qd, attn, qd, nullptr, nullptr, x, H, x, H, H, qd, EPI_NONE, B));
                 launch_rmsnorm<T>(st, x, L.post_norm, xn, B, H, c.rms_eps);
@@ -1111,7 +1085,6 @@ public:
     int batch_submit(int env, int max_new, const int64_t* eos, int n_eos) override {
         Env& e = env_at(env);
         REQUIRE(weights_missing() == 0, g_err);
-        ensure_tiled();
         REQUIRE(max_new >= 1, "max_new_tokens must be >= 1");
         REQUIRE(e.n_embeds - e.kv_len >= 1, "nothing to prefill for this env (append its turn first)");
         int slot = -1;
@@ -1327,7 +1300,6 @@ public:
     void generate(int env, int max_new, const int64_t* eos, int n_eos, int64_t* out, int cap, int32_t* n_out, bool fixed) override {
         Env& e = env_at(env);
         REQUIRE(weights_missing() == 0, g_err);
-        ensure_tiled();
         const int P = e.kv_len, L = e.n_embeds, Tn = L - P;
         REQUIRE(Tn >= 1, "nothing to prefill: inputs_embeds not longer than the KV cache");
         REQUIRE(max_new >= 1 && cap >= 1, "max_new_tokens must be >= 1");
@@ -1497,8 +1469,7 @@ public:
     // act8_src: the rows whose e4m3 copy act8 currently holds because the reduce that produced them also quantised them (the normalised
     // rows handed from o_proj to gate/up and from down_proj to the next layer's qkv: two of the four quantise launches of a layer)
     const void* act8_src = nullptr; int act8_rows = 0;
-    bool llm_gemm(GemmArgs a, const Q8& q, const T* wt) {
-        a.Wt = wt;                 // (the launcher keeps it only for the single-row-tile bf16 / fp32 kernels)
+    bool llm_gemm(GemmArgs a, const Q8& q) {
         if (fp8_gemm_on && q.q) {
             if (!(act8_src == a.A && act8_rows == a.M && a.lda == a.K)) launch_quant_fp8_rows(st, a.A, a.lda, act8, act8_scale, a.M, a.K);
             act8_src = nullptr;
@@ -1566,18 +1537,6 @@ public:
         }
         const bool fused = launch_gemm<T>(st, a);
         sync();
-        return fused;
-    }
-    // the product with W read from its stage-major tiled copy (built here into scratch memory): what the engine's M <= 256 LLM products run
-    bool op_gemm_tiled(const GemmArgs& a0) override {
-        REQUIRE(tiles(a0.N, a0.K) && a0.M >= 1 && a0.M <= 256, "tiled weights: N % 128 == 0, K a whole number of 128-byte stages, M <= 256");
-        void* wt = nullptr;
-        HIP_CHECK(hipMalloc(&wt, (size_t)a0.N * a0.K * sizeof(T)));
-        launch_tile_pack<T>(st, a0.W, a0.ldw, a0.N, a0.K, wt);
-        GemmArgs a = a0; a.Wt = wt;
-        bool fused = false;
-        try { fused = op_gemm(a); } catch (...) { (void)hipFree(wt); throw; }
-        HIP_CHECK(hipFree(wt));
         return fused;
     }
     void op_gemv(GemvArgs a, int32_t* host_token) override {
@@ -1771,15 +1730,6 @@ int svln_op_gemm_norm(svln_engine* h, const void* A, int lda, const void* W, int
     a.M = M; a.N = N; a.K = K; a.epi = EPI_NONE; a.nsplit = 1; a.force_split = force_split; a.norm_w = norm_w; a.norm_out = norm_out; a.norm_eps = eps;
     const bool f = h->impl->op_gemm(a);
     if (fused) *fused = f ? 1 : 0;
-    API_END
-}
-int svln_op_gemm_tiled(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res, int ldr,
-                       int M, int N, int K, int epi, int force_split) {
-    API_BEGIN_H
-    GemmArgs a; std::memset(&a, 0, sizeof(a));
-    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.res = res; a.ldr = ldr;
-    a.M = M; a.N = N; a.K = K; a.epi = epi; a.nsplit = 1; a.force_split = force_split; a.pen = 1.0f;
-    h->impl->op_gemm_tiled(a);
     API_END
 }
 int svln_op_gemm_norm_q8(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* res, int ldr,

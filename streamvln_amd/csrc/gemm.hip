@@ -31,18 +31,12 @@ namespace svln {
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1, int NA_ = 0, int NW_ = 0> struct TileCfg {
+template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1> struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ROWB = ROWB_;
     // KG > 1: K is split INSIDE the workgroup: KG groups of WM x WN waves each run the stage pipeline (own LDS ring) over 1/KG of the K
     // stages of the same output tile and exchange their accumulators through LDS at the end -- the shorter K chain of a split-K launch
     // without fp32 slabs in HBM and without a second (reduce) launch
     static constexpr int KG = KG_;
-    // NA, NW > 0: ASYMMETRIC rings (single-row-tile products, M <= 256): the activation tile (L2-resident, re-read by every column tile)
-    // and the weight tile (streamed from HBM once) get separate LDS rings of NA and NW buffers, and separate loader waves (half of the
-    // waves issue only weight pieces, the other half only activation pieces), so each keeps its own counted vmcnt: NW - 1 weight stages
-    // stay in flight (64 KB per CU instead of 32 KB with the shared 3-deep ring) while the activation tile is fetched one stage ahead.
-    static constexpr int NA = NA_, NW = NW_;
-    static constexpr bool ASYM = NA_ > 0;
     static constexpr bool DEEP = DEEP_;
     static constexpr int NBUF = NBUF_;                        // LDS ring depth of the direct-to-LDS (glds) pipeline
     // ILV: the fragment reads of macro step s+1 are issued one per gap between the MFMAs of step s instead of as one burst before
@@ -54,14 +48,13 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, 
     static constexpr int SH = ROWS_PER_BANKROW == 2 ? 1 : 2;
     static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     static constexpr int A_LOADS = BM * CH / (THREADS / KG), W_LOADS = BN * CH / (THREADS / KG);
-    static constexpr int LDS_BYTES = NA_ > 0 ? (NA_ * BM + NW_ * BN) * ROWB : KG * NBUF * STAGE_BYTES;
+    static constexpr int LDS_BYTES = KG * NBUF * STAGE_BYTES;
     static constexpr int MI = BM / WM / 32, NJ = BN / WN / 32;   // 32x32 accumulator tiles per wave
     static_assert(BM / WM % 32 == 0 && BN / WN % 64 == 0, "wave tile: rows a multiple of 32, columns a multiple of 64 ([gate 32 | up 32] blocks for SwiGLU)");
     static_assert(BM * CH % (THREADS / KG) == 0 && BN * CH % (THREADS / KG) == 0, "staging must divide evenly");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
-using Cfg256A = TileCfg<256, 128, 4, 2, 128, true, 3, false, 1, 3, 4>;   // the same tile with asymmetric rings: 2 x 32 KB activation + 5 x 16 KB weight buffers (144 KB)
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
 using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
@@ -282,9 +275,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // A template parameter, not a run-time flag: a branch around the DMA issue of the large-tile kernels cost the window-restart prefill 2.5 ms.
 // VP: the fused K / V^T packing tail of the SigLIP QKV product (a template parameter: as a run-time flag its tests sat in the store loop of
 // every plain epilogue and cost the window-restart turn 2.8 ms).
-// TW: the weight tile comes from the stage-major tiled copy p.Wt (GemmArgs::Wt): piece b of stage st of column tile bn is the contiguous
-// KiB at ((bn * stages + st) * BN * 128 B) + b * 1 KiB, lane l its chunk l -- no row stride, no source swizzle (the copy is pre-swizzled).
-template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false, bool TW = false>
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
@@ -331,48 +322,27 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     const int n = max(st_end - st_begin, 0);
 
     // per-lane source pointers (at K stage 0) and wave-uniform LDS offsets of this wave's 1-KiB blocks
-    constexpr bool ASYM = C::ASYM;
-    static_assert(!ASYM || (KG == 1 && WAVES % 2 == 0 && BLK_W % (WAVES / 2) == 0 && BLK_A % (WAVES / 2) == 0), "asymmetric rings: half the waves per operand");
-    constexpr int PW_W = ASYM ? BLK_W / (WAVES / 2) : 0, PW_A = ASYM ? BLK_A / (WAVES / 2) : 0;      // pieces per stage of a weight / activation loader wave
-    constexpr int NSRC = ASYM ? (PW_A > PW_W ? PW_A : PW_W) : PER_WAVE;
-    constexpr int A_STAGE = C::BM * C::ROWB, W_STAGE = C::BN * C::ROWB;
-    const bool w_wave = ASYM && wave < WAVES / 2;                 // (wave-uniform)
-    const char* src[NSRC];
-    int cj[NSRC], loff[NSRC];
-    if constexpr (ASYM) {
+    const char* src[PER_WAVE];
+    int cj[PER_WAVE], loff[PER_WAVE];
 #pragma unroll
-        for (int j = 0; j < NSRC; ++j) {
-            const int blk = (w_wave ? wave : wave - WAVES / 2) + (WAVES / 2) * j;
-            const int row = blk * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
-            cj[j] = c;
-            loff[j] = blk * 1024;
-            if (w_wave) src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;      // (j < PW_W used)
-            else src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int b = wave + WAVES * j;
-            const bool isA = b < BLK_A;
-            const int blk = isA ? b : b - BLK_A;
-            const int row = blk * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
-            cj[j] = c;
-            loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
-            if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
-            else if (TW) src[j] = (const char*)p.Wt + (size_t)bn * stages_total * W_STAGE + (size_t)blk * 1024 + lane * 16;
-            else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
-        }
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int b = wave + WAVES * j;
+        const bool isA = b < BLK_A;
+        const int blk = isA ? b : b - BLK_A;
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> C::SH) & (C::CH - 1));
+        cj[j] = c;
+        loff[j] = (isA ? 0 : C::BM * C::ROWB) + blk * 1024;
+        if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
+        else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
     }
-    static_assert(!TW || (NTW && !ASYM && sizeof(TA) == sizeof(T)), "tiled weights: the single-row-tile kernels, engine operand type");
     auto issue = [&](int st, int buf) {
         char* base = ring + buf * C::STAGE_BYTES;
         const bool full = (st + 1) * C::CH <= kchunks;
         if (full) {                       // every stage but a ragged last one: no per-lane source select in front of the DMA instructions
 #pragma unroll
             for (int j = 0; j < PER_WAVE; ++j) {
-                const char* g = src[j] + (size_t)st * ((TW && j >= BLK_A / WAVES) ? W_STAGE : C::ROWB);      // (tiled weights: K is whole stages)
+                const char* g = src[j] + (size_t)st * C::ROWB;
                 if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
                 else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
             }
@@ -386,48 +356,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             // 6.80 -> 6.63 ms); the activation panel, re-read by every workgroup, stays cached
             if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
             else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
-        }
-    };
-    // asymmetric rings: one operand's pieces of stage `st` into buffer `buf` of that operand's ring (weights non-temporal when NTW)
-    auto issue_w = [&](int st, int buf) {
-        char* base = smem + C::NA * A_STAGE + buf * W_STAGE;
-        if ((st + 1) * C::CH <= kchunks) {          // full stage: no per-lane source select in front of the DMA instructions
-#pragma unroll
-            for (int j = 0; j < PW_W; ++j) {
-                const char* g = src[j] + (size_t)st * C::ROWB;
-                if (NTW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
-                else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < PW_W; ++j) {
-            const char* g = src[j] + (size_t)st * C::ROWB;
-            if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
-            if (NTW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
-            else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
-        }
-    };
-    // activation pieces: 8-row blocks that lie wholly past row M are not fetched at all (at M = 212, 5 of the 32 blocks of the 256-row tile):
-    // their LDS rows keep stale bytes, which only feed accumulator rows that are never stored.  The activation waves wait with vmcnt(0), so
-    // a wave-dependent piece count needs no change of the wait.
-    const int a_blk0 = wave - WAVES / 2, a_rows = p.M - row0;
-    auto issue_a = [&](int st, int buf) {
-        char* base = smem + buf * A_STAGE;
-        if ((st + 1) * C::CH <= kchunks) {
-#pragma unroll
-            for (int j = 0; j < PW_A; ++j) {
-                if (C::NA == 2 && (a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;       // (wave-uniform; only with a full drain per stage: the counted wait assumes PW_A pieces)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[j] + (size_t)st * C::ROWB), (lds_ptr_t)(base + loff[j]), 16, 0, 0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < PW_A; ++j) {
-            if (C::NA == 2 && (a_blk0 + (WAVES / 2) * j) * 8 >= a_rows) continue;
-            const char* g = src[j] + (size_t)st * C::ROWB;
-            if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
         }
     };
 
@@ -457,17 +385,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int rw_ = wc * WCOLS + j * 32 + r32;
-            offW[s][j] = lds0 + (ASYM ? C::NA * A_STAGE : C::BM * C::ROWB) + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
+            offW[s][j] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
         }
     }
     // fragments double-buffered by macro step: the reads of step s+1 are in flight under the MFMAs of step s
     u32x4 fa[2][MI], fb[2][NJ];
-    // bo / bow: byte offset of the stage buffer inside the activation / weight ring (one shared ring: bow == bo)
-    auto read_step = [&](int s, unsigned bo, unsigned bow) {
+    auto read_step = [&](int s, unsigned bo) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bow));
+        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
     };
     auto wait_step = [&](int k, bool more) {          // step in buffer k landed (`more`: the next step's RD reads stay in flight)
         if constexpr (MI == 4 && NJ == 4) {
@@ -485,18 +412,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
     // one fragment read of step s (A fragments first, then W)
-    auto read_one = [&](int s, int q, unsigned bo, unsigned bow) {
+    auto read_one = [&](int s, int q, unsigned bo) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             if (q == i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bow));
+            if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
     };
     // after_first_reads: the DMA issue of a later stage, placed behind the first fragment reads of this one so that its address arithmetic
     // (8 loads x ~8 VALU + the m0 set-up per wave, all waves at once right after the barrier) runs under their LDS latency
-    auto compute = [&](unsigned bo, unsigned bow, auto&& after_first_reads) {
-        read_step(0, bo, bow);
+    auto compute = [&](int buf, auto&& after_first_reads) {
+        const unsigned bo = buf * C::STAGE_BYTES;
+        read_step(0, bo);
         after_first_reads();
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
@@ -510,15 +438,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                     for (int j = 0; j < NJ; ++j) {
                         const u32x4 a4 = fa[s & 1][i], b4 = fb[s & 1][j];
                         mma_chunk<TA>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
-                        if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo, bow);
+                        if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo);
                         ++q;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 if (s + 1 < STEPS)
-                    for (; q < RD; ++q) read_one(s + 1, q, bo, bow);
+                    for (; q < RD; ++q) read_one(s + 1, q, bo);
                 continue;
             }
-            if (s + 1 < STEPS) read_step(s + 1, bo, bow);
+            if (s + 1 < STEPS) read_step(s + 1, bo);
             wait_step(s & 1, s + 1 < STEPS);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -531,44 +459,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
 
-    if constexpr (ASYM) {
-        // Weight-loader waves keep DW stages in flight, activation-loader waves one; each wave's counted vmcnt sees only its own operand.
-        // Stage i may be read after: every weight wave has waited for its pieces of W(i), every activation wave for its pieces of A(i),
-        // and the barrier.  A buffer is refilled one iteration after its last read (the barrier in between), as in the shared ring.
-        constexpr int DW = C::NW - 1, DA = C::NA - 1;
-        static_assert(DA >= 1 && DA <= 2 && DW >= 1 && DW <= 4, "1..2 activation stages, 1..4 weight stages in flight");
-        if (w_wave) {
-#pragma unroll
-            for (int d = 0; d < DW; ++d)
-                if (d < n) issue_w(st_begin + d, d);
-        } else {
-#pragma unroll
-            for (int d = 0; d < DA; ++d)
-                if (d < n) issue_a(st_begin + d, d);
-        }
-        int bw = 0, bwn = DW % C::NW, ba = 0, ban = DA % C::NA;
-        for (int i = 0; i < n; ++i) {
-            if (w_wave) {
-                const int rem = min(DW - 1, n - 1 - i);            // weight stages that may stay in flight behind stage i
-                if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW_W) : "memory");
-                else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW_W) : "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PW_W) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (DA > 1 && min(DA - 1, n - 1 - i) >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW_A) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            compute(ba * A_STAGE, bw * W_STAGE, [&]() {
-                if (w_wave) { if (i + DW < n) issue_w(st_begin + i + DW, bwn); }
-                else if (i + DA < n) issue_a(st_begin + i + DA, ban);
-            });
-            ba = ba + 1 == C::NA ? 0 : ba + 1;
-            ban = ban + 1 == C::NA ? 0 : ban + 1;
-            bw = bw + 1 == C::NW ? 0 : bw + 1;
-            bwn = bwn + 1 == C::NW ? 0 : bwn + 1;
-        }
-    } else {
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) issue(st_begin + d, d);
@@ -578,10 +468,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (KG > 1 && i >= n) continue;               // a K-group with one stage less keeps the barrier count of the others
-        compute(buf * C::STAGE_BYTES, buf * C::STAGE_BYTES, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
+        compute(buf, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
-    }
     }
     if constexpr (KG > 1) {
         // Exchange between the two K-groups: group g finishes accumulator rows i with i / (MI / KG) == g, so it hands the OTHER rows to its
@@ -1040,16 +929,11 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         }
     }
     constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value;      // the single-row-tile configurations
-    // force_cfg | 0x4000: the asymmetric-ring form of the 256x128 tile (measured no faster than the shared 3-deep ring: DESIGN.md 4.1; kept
-    // reachable for tests / A-B)
-    using CN = typename std::conditional<std::is_same<C, Cfg256>::value, Cfg256A, C>::type;
-    const bool asym = std::is_same<C, Cfg256>::value && (a.force_cfg & 0x4000);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
             if constexpr (HAS_NTW) {
                 if (a.nt_w) {
-                    if (asym) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CN, SPLITK, fp8_t, true>), dim3(wgs), dim3(CN::THREADS), CN::LDS_BYTES, s, a);
-                    else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
                     return;
                 }
             }
@@ -1058,13 +942,8 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         }
     }
     if constexpr (HAS_NTW) {
-        if (a.nt_w && a.Wt && !asym) {      // stage-major weight copy (launch_epi keeps Wt only for shapes it is valid for)
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true, false, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
-            return;
-        }
         if (a.nt_w) {
-            if (asym) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, CN, SPLITK, T, true>), dim3(wgs), dim3(CN::THREADS), CN::LDS_BYTES, s, a);
-            else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
             return;
         }
     }
@@ -1103,8 +982,6 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return false;
     a.vp_on = 0;
     a.nt_w = a.M <= 256 ? 1 : 0;          // the heuristics below give such products ONE row tile (256x128 or 32x128 tiles)
-    if (!(a.nt_w && !a.a_scale && a.zeros && a.N % 128 == 0 && a.K % (8 * Elt<T>::PER_CHUNK) == 0 && !(a.force_cfg & 0x2000))) a.Wt = nullptr;
-    if (a.force_cfg & 0x8000) a.Wt = nullptr;      // tests / A-B: row-major weights only
     const int EPC = a.a_scale ? 16 : Elt<T>::PER_CHUNK;      // 16-byte chunks of K: e4m3 operands hold 16 values per chunk
     a.tile_base = 0;
     if (a.force_split > 1) {      // a forced split obeys the same workspace / shape limits as the heuristic ones
@@ -1232,39 +1109,12 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
 
 }  // namespace
 
-namespace {
-// row-major W -> stage-major tiled copy (GemmArgs::Wt).  One thread = one 16-byte chunk of the image: chunk l of piece b of stage st of
-// column tile t holds W[t*128 + b*8 + l/8][(st*8 + ((l%8) ^ swizzle(row))) chunks], the swizzle of the 128-byte-row LDS tiles (swz<>).
-template <typename T>
-__global__ __launch_bounds__(256) void tile_pack_kernel(const T* W, int ldw, int tiles_n, int stages, T* Wt) {
-    constexpr int EPC = Elt<T>::PER_CHUNK;
-    const size_t total = (size_t)tiles_n * stages * 1024;
-    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
-        const int within = (int)(id & 1023), st = (int)((id >> 10) % stages), t = (int)((id >> 10) / stages);
-        const int b = within >> 6, l = within & 63, row = b * 8 + (l >> 3);
-        const int c = (l & 7) ^ ((row >> Cfg256::SH) & 7);
-        *(uint4*)(Wt + id * EPC) = *(const uint4*)(W + (size_t)(t * 128 + row) * ldw + (size_t)(st * 8 + c) * EPC);
-    }
-}
-}  // namespace
-template <typename T> void launch_tile_pack(hipStream_t s, const void* W, int ldw, int N, int K, void* Wt) {
-    const int tiles_n = N / 128, stages = K / (8 * Elt<T>::PER_CHUNK);
-    const size_t total = (size_t)tiles_n * stages * 1024;
-    int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-    hipLaunchKernelGGL((tile_pack_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)W, ldw, tiles_n, stages, (T*)Wt);
-}
-template void launch_tile_pack<bf16>(hipStream_t, const void*, int, int, int, void*);
-template void launch_tile_pack<float>(hipStream_t, const void*, int, int, int, void*);
-
 // lm_head of <= 32 rows (envs decoded together) with the arg-max in the epilogue: one pass of 32x128 tiles over the vocabulary, the weight
 // tile staged non-temporally, no C.  Returns the number of column tiles (= partials per row).
 template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a) {
     a.nt_w = 1; a.tile_base = 0; a.nsplit = 1; a.vp_on = 0;
     a.launch_tiles = (a.N + 127) / 128;
-    if (a.Wt && a.N % 128 == 0 && a.K % (8 * Elt<T>::PER_CHUNK) == 0 && !(a.force_cfg & 0x8000))
-        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true, false, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
-    else
-        hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
     return a.launch_tiles;
 }
 template int launch_gemm_argmax<bf16>(hipStream_t, GemmArgs);
@@ -1290,12 +1140,6 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true, false, true>, Cfg256::LDS_BYTES, Cfg256::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true, false, true>, Cfg256::LDS_BYTES, Cfg256::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true, false, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true, false, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, false, T, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, true, T, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
@@ -1311,8 +1155,6 @@ template <typename T, int EPI> static void gemm_attr() {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, false, fp8_t, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256A, true, fp8_t, true>, Cfg256A::LDS_BYTES, Cfg256A::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
@@ -1325,7 +1167,6 @@ template <typename T, int EPI> static void gemm_attr() {
 }
 template <typename T> static void gemm_argmax_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true, false, true>, CfgSkinny::LDS_BYTES, CfgSkinny::THREADS);
 }
 void gemm_init_attrs() {
     gemm_argmax_attr<bf16>(); gemm_argmax_attr<float>();

@@ -53,18 +53,11 @@ struct GemmArgs {
     // penalty as in GemvBatchArgs.
     float* part_val = nullptr; int* part_idx = nullptr;
     const uint8_t* pen_flags = nullptr; const int* pen_rows = nullptr; float pen = 1.0f;
-    // optional second copy of W in STAGE-MAJOR order (launch_tile_pack): for every 128-column tile and every 128-byte K stage the
-    // 128 x 128 B block is stored contiguously, already in the swizzled LDS image order, so a stage's weight DMA is one contiguous 16 KiB
-    // read from HBM instead of 128 pieces of 128 B that lie a row stride apart.  Used by the single-row-tile kernels (M <= 256: steady
-    // prefill, batched decode) when N % 128 == 0 and K is a whole number of stages; the row-major copy stays the source of every other kernel.
-    const void* Wt = nullptr;
     VitPackArgs vp; int vp_on;    // filled by the launcher: device-side copy of *vitpack for the unsplit kernels that pack in their epilogue
     int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 129 -> 128x128 tiles with two in-workgroup K groups; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced
-template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a);
-// W [N][K] row-major (ld = ldw) -> the stage-major tiled copy described at GemmArgs::Wt (N % 128 == 0, K % (elements per 128 B) == 0)
-template <typename T> void launch_tile_pack(hipStream_t s, const void* W, int ldw, int N, int K, void* Wt);    // EPI_ARGMAX form (M <= 32); returns the partials per row
+template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a);    // EPI_ARGMAX form (M <= 32); returns the partials per row
 
 // y[N] = epi(W[N,K] . x'[K] + bias) + res,  x' = x or rmsnorm(x) * norm_w (fused prologue).
 // EPI_SWIGLU as above (y has N/2 entries).  EPI_ARGMAX: no y; per-workgroup (max, lowest index)
