@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_diag
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-GROUPS=(
+CGRP=(
  "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
  "SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS SQ_BUSY_CYCLES"
  "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
@@ -19,7 +19,7 @@ GROUPS=(
 for SH in "$@"; do
   export KBENCH_SHAPES="$SH"
   g=0
-  for G in "${GROUPS[@]}"; do
+  for G in "${CGRP[@]}"; do
     rocprofv3 --pmc $G --output-format csv -d $OUT/g$g -- python3 tools/kbench.py gemm 6 > $OUT/g$g.log 2>&1 || echo "group $g failed ($G)" >> $GRAFT_REPO_ROOT/gpurun_out/pmc_diag.txt
     g=$((g+1))
   done
