@@ -275,12 +275,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // A template parameter, not a run-time flag: a branch around the DMA issue of the large-tile kernels cost the window-restart prefill 2.5 ms.
 // VP: the fused K / V^T packing tail of the SigLIP QKV product (a template parameter: as a run-time flag its tests sat in the store loop of
 // every plain epilogue and cost the window-restart turn 2.8 ms).
-// WR (single-row-tile products, M <= 256; with NTW): the WEIGHT tile does not go through LDS-DMA.  Measured (tools/pmc_diag.sh, DESIGN.md
-// 4.1): a CU keeps only ~64 LDS-DMA lines (8 KB) in flight, so its DMA rate is 8 KB / latency -- 70 GB/s for the L2-resident activation
-// panel (~250 cycles) but 17-19 GB/s for weights that come from HBM (~1000 cycles), and the stage time is the SUM of both.  Here every wave
-// loads its weight chunks HBM -> VGPR with ordinary 16-byte loads (inline asm, non-temporal) DW = 4 stages ahead -- those are not subject to
-// the DMA cap -- and copies them into a 2-deep LDS buffer one stage before their use; the activation tile stays on the LDS-DMA ring.
-template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false, bool WR = false>
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false>
 __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elt<TA>::PER_CHUNK;                   // TA = operand storage (T, or fp8_t with per-row scales applied in the epilogue)
@@ -341,18 +336,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         if (isA) src[j] = (const char*)((const TA*)p.A + (size_t)min(row0 + row, p.M - 1) * p.lda) + c * 16;
         else src[j] = (const char*)((const TA*)p.W + (size_t)min(col0 + row, p.N - 1) * p.ldw) + c * 16;
     }
-    constexpr int NAL = BLK_A / WAVES, NWL = BLK_W / WAVES;      // activation / weight blocks per wave and stage (j < NAL: activation)
-    constexpr int A_STAGE = C::BM * C::ROWB, W_STAGE = C::BN * C::ROWB;
-    constexpr int DW = 4;                                         // WR: weight stages in flight in registers
-    static_assert(!WR || (NTW && KG == 1 && BLK_A % WAVES == 0 && BLK_W % WAVES == 0), "register-staged weights: the single-row-tile kernels");
-    constexpr int NISS = WR ? NAL : PER_WAVE;                     // LDS-DMA pieces per wave and stage
-    constexpr int ISS_STRIDE = WR ? A_STAGE : C::STAGE_BYTES;     // WR: the ring holds activation tiles only; 2 weight buffers follow it
     auto issue = [&](int st, int buf) {
-        char* base = ring + buf * ISS_STRIDE;
+        char* base = ring + buf * C::STAGE_BYTES;
         const bool full = (st + 1) * C::CH <= kchunks;
         if (full) {                       // every stage but a ragged last one: no per-lane source select in front of the DMA instructions
 #pragma unroll
-            for (int j = 0; j < NISS; ++j) {
+            for (int j = 0; j < PER_WAVE; ++j) {
                 const char* g = src[j] + (size_t)st * C::ROWB;
                 if (NTW && j >= BLK_A / WAVES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 2);
                 else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + loff[j]), 16, 0, 0);
@@ -360,7 +349,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
             return;
         }
 #pragma unroll
-        for (int j = 0; j < NISS; ++j) {
+        for (int j = 0; j < PER_WAVE; ++j) {
             const char* g = src[j] + (size_t)st * C::ROWB;
             if (st * C::CH + cj[j] >= kchunks) g = (const char*)p.zeros;
             // NTW: the weight blocks (j >= BLK_A / WAVES for every wave) non-temporal, aux = 2 (measured inside the turn: steady prefill
@@ -396,17 +385,16 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int rw_ = wc * WCOLS + j * 32 + r32;
-            offW[s][j] = lds0 + (WR ? C::NBUF * A_STAGE : C::BM * C::ROWB) + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
+            offW[s][j] = lds0 + C::BM * C::ROWB + rw_ * C::ROWB + swz<C>(rw_, 2 * s + h);
         }
     }
     // fragments double-buffered by macro step: the reads of step s+1 are in flight under the MFMAs of step s
     u32x4 fa[2][MI], fb[2][NJ];
-    // bo / bow: byte offset of the stage's activation / weight tile (one shared ring: bow == bo)
-    auto read_step = [&](int s, unsigned bo, unsigned bow) {
+    auto read_step = [&](int s, unsigned bo) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bow));
+        for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
     };
     auto wait_step = [&](int k, bool more) {          // step in buffer k landed (`more`: the next step's RD reads stay in flight)
         if constexpr (MI == 4 && NJ == 4) {
@@ -424,18 +412,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
     // one fragment read of step s (A fragments first, then W)
-    auto read_one = [&](int s, int q, unsigned bo, unsigned bow) {
+    auto read_one = [&](int s, int q, unsigned bo) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             if (q == i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s & 1][i]) : "v"(offA[s][i] + bo));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bow));
+            if (q == MI + j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s & 1][j]) : "v"(offW[s][j] + bo));
     };
     // after_first_reads: the DMA issue of a later stage, placed behind the first fragment reads of this one so that its address arithmetic
     // (8 loads x ~8 VALU + the m0 set-up per wave, all waves at once right after the barrier) runs under their LDS latency
-    auto compute = [&](unsigned bo, unsigned bow, auto&& after_first_reads) {
-        read_step(0, bo, bow);
+    auto compute = [&](int buf, auto&& after_first_reads) {
+        const unsigned bo = buf * C::STAGE_BYTES;
+        read_step(0, bo);
         after_first_reads();
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
@@ -449,15 +438,15 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                     for (int j = 0; j < NJ; ++j) {
                         const u32x4 a4 = fa[s & 1][i], b4 = fb[s & 1][j];
                         mma_chunk<TA>(make_uint4(a4.x, a4.y, a4.z, a4.w), make_uint4(b4.x, b4.y, b4.z, b4.w), acc[i][j]);
-                        if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo, bow);
+                        if (s + 1 < STEPS && q < RD) read_one(s + 1, q, bo);
                         ++q;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 if (s + 1 < STEPS)
-                    for (; q < RD; ++q) read_one(s + 1, q, bo, bow);
+                    for (; q < RD; ++q) read_one(s + 1, q, bo);
                 continue;
             }
-            if (s + 1 < STEPS) read_step(s + 1, bo, bow);
+            if (s + 1 < STEPS) read_step(s + 1, bo);
             wait_step(s & 1, s + 1 < STEPS);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -470,80 +459,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
 
-    if constexpr (WR) {
-        // ---- weights through registers (see the comment at the kernel head).  Per stage a wave issues NAL activation DMA pieces (for stage
-        // i + 2) and NWL weight loads (for stage i + DW), then copies the weight chunks of stage i + 1 -- loaded DW - 1 stages ago -- into
-        // the weight buffer that stage i - 1 has just finished with.  vmcnt counts DMA pieces and loads together, in issue order.
-        u32x4 wreg[DW][NWL];
-        const unsigned w_lds = lds0 + C::NBUF * A_STAGE + lane * 16;
-        auto load_w = [&](auto slot, int st) {
-            constexpr int k = decltype(slot)::value;
-            const bool full = (st + 1) * C::CH <= kchunks;
-#pragma unroll
-            for (int j = 0; j < NWL; ++j) {
-                const char* g = src[NAL + j] + (size_t)st * C::ROWB;
-                if (!full && st * C::CH + cj[NAL + j] >= kchunks) g = (const char*)p.zeros;
-                u32x4& dst = wreg[k][j];               // (named before the asm: operands alone do not capture into the lambda)
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(g) : "memory");
-            }
-        };
-        auto store_w = [&](auto slot, int wbuf) {
-            constexpr int k = decltype(slot)::value;
-#pragma unroll
-            for (int j = 0; j < NWL; ++j) {
-                const unsigned addr = w_lds + (unsigned)(wbuf * W_STAGE + loff[NAL + j] - C::BM * C::ROWB);
-                const u32x4& val = wreg[k][j];
-                asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(val) : "memory");
-            }
-        };
-        // The waits carry NO register operands: with "+v" ties hipcc merged the differently-counted waits of the branches below through
-        // copies of the destination registers placed BEFORE the wait (stale data).  Every producer (load) and consumer (ds_write) of wreg
-        // is an asm volatile statement, and those keep their program order; tests/test_asm_guard.py checks the generated code.
-        auto landed = [&](auto, auto cnt) {               // at most `cnt` younger vector-memory operations of this wave remain in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(cnt)::value) : "memory");
-        };
-        using I0 = std::integral_constant<int, 0>;
-        // prologue: W(0), A(0), A(1), W(1), W(2), W(3)
-        if (n > 0) load_w(I0{}, st_begin);
-        if (n > 0) issue(st_begin, 0);
-        if (n > 1) issue(st_begin + 1, 1);
-        if (n > 1) load_w(std::integral_constant<int, 1>{}, st_begin + 1);
-        if (n > 2) load_w(std::integral_constant<int, 2>{}, st_begin + 2);
-        if (n > 3) load_w(std::integral_constant<int, 3>{}, st_begin + 3);
-        if (n > 0) {
-            if (n >= DW) landed(I0{}, std::integral_constant<int, 2 * NAL + 3 * NWL>{});
-            else landed(I0{}, I0{});
-            store_w(I0{}, 0);
-        }
-        int ba = 0, ban = 2 % C::NBUF;                 // activation ring buffer of stage i / of stage i + 2
-        auto stage = [&](auto kc, int i) {             // stage i, i % DW == kc
-            constexpr int k = decltype(kc)::value, k1 = (k + 1) % DW;
-            using K1 = std::integral_constant<int, k1>;
-            // needed now: this wave's pieces of A(i) and its chunks of W(i + 1).  Younger than both: W(i + 2), then A(i + 1) and W(i + 3)
-            // (stage 0: only W(2), W(3) behind W(1), the prologue's order); short tails drain.
-            if (i + 1 < n) {
-                if (i == 0 && n >= DW) landed(K1{}, std::integral_constant<int, 2 * NWL>{});
-                else if (i > 0 && i + 3 < n) landed(K1{}, std::integral_constant<int, NAL + 2 * NWL>{});
-                else landed(K1{}, I0{});
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            compute(ba * A_STAGE, (i & 1) * W_STAGE, [&]() {
-                if (i + 2 < n) issue(st_begin + i + 2, ban);
-                if (i + DW < n) load_w(kc, st_begin + i + DW);
-                if (i + 1 < n) store_w(K1{}, (i + 1) & 1);
-            });
-            ba = ba + 1 == C::NBUF ? 0 : ba + 1;
-            ban = ban + 1 == C::NBUF ? 0 : ban + 1;
-        };
-        for (int i = 0; i < n; i += DW) {
-            stage(std::integral_constant<int, 0>{}, i);
-            if (i + 1 < n) stage(std::integral_constant<int, 1>{}, i + 1);
-            if (i + 2 < n) stage(std::integral_constant<int, 2>{}, i + 2);
-            if (i + 3 < n) stage(std::integral_constant<int, 3>{}, i + 3);
-        }
-    } else {
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) issue(st_begin + d, d);
@@ -553,10 +468,9 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (KG > 1 && i >= n) continue;               // a K-group with one stage less keeps the barrier count of the others
-        compute(buf * C::STAGE_BYTES, buf * C::STAGE_BYTES, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
+        compute(buf, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
-    }
     }
     if constexpr (KG > 1) {
         // Exchange between the two K-groups: group g finishes accumulator rows i with i / (MI / KG) == g, so it hands the OTHER rows to its
@@ -1015,18 +929,8 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
         }
     }
     constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value;      // the single-row-tile configurations
-    // 256x128 single-row-tile products stage their weights through registers (WR); force_cfg | 0x4000 keeps them on the LDS-DMA ring
-    constexpr bool HAS_WR = std::is_same<C, Cfg256>::value;
-    constexpr int WR_LDS = C::NBUF * C::BM * C::ROWB + 2 * C::BN * C::ROWB;
-    const bool wr = HAS_WR && a.nt_w && !(a.force_cfg & 0x4000);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
-            if constexpr (HAS_WR) {
-                if (wr) {
-                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true, false, true>), dim3(wgs), dim3(C::THREADS), WR_LDS, s, a);
-                    return;
-                }
-            }
             if constexpr (HAS_NTW) {
                 if (a.nt_w) {
                     hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
@@ -1034,12 +938,6 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
                 }
             }
             hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
-            return;
-        }
-    }
-    if constexpr (HAS_WR) {
-        if (wr) {
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true, false, true>), dim3(wgs), dim3(C::THREADS), WR_LDS, s, a);
             return;
         }
     }
@@ -1242,8 +1140,6 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, T, true, false, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, T, true, false, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, T, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
@@ -1259,8 +1155,6 @@ template <typename T, int EPI> static void gemm_attr() {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t, true, false, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-        set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true, fp8_t, true, false, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true, fp8_t, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false, fp8_t>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);

@@ -32,7 +32,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (32, 0), (32, 4), (64, 0), (129, 0), (0x4000, 0), (0x4000, 3)])   # 0x4000 = M <= 256: weights on the LDS-DMA ring instead of through registers; 0x2000 = register-staged kernel; 256 = 256x256 tiles; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
