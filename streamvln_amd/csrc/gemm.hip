@@ -31,7 +31,9 @@ namespace svln {
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1> struct TileCfg {
+template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, bool ILV_ = false, int KG_ = 1, bool P8_ = false> struct TileCfg {
+    // P8: the 8-phase schedule of p8_mainloop (256x256 tile, bf16 operands) instead of the stage ring
+    static constexpr bool P8 = P8_;
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ROWB = ROWB_;
     // KG > 1: K is split INSIDE the workgroup: KG groups of WM x WN waves each run the stage pipeline (own LDS ring) over 1/KG of the K
     // stages of the same output tile and exchange their accumulators through LDS at the end -- the shorter K chain of a split-K launch
@@ -56,6 +58,8 @@ template <int BM_, int BN_, int WM_, int WN_, int ROWB_, bool DEEP_, int NBUF_, 
 using Cfg128 = TileCfg<128, 128, 2, 2, 128, false, 2>;
 using Cfg256 = TileCfg<256, 128, 4, 2, 128, true, 3>;
 using CfgBig = TileCfg<256, 256, 2, 4, 128, false, 2, true>;
+using Cfg8P = TileCfg<256, 256, 2, 4, 128, false, 2, false, 1, true>;   // same tile, p8_mainloop schedule (bf16 operands, M > 512), 16x16x32 MFMAs
+using Cfg8P32 = TileCfg<256, 256, 2, 4, 128, false, 2, true, 1, true>;  // ... with 32x32x16 MFMAs (bit-identical to the stage ring; A/B and tests)
 using Cfg128L = TileCfg<128, 128, 2, 2, 128, false, 2, true>;  // Cfg128 for more than one round of tiles
 using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (32x64 wave tiles), five 16 KB stages in flight: >= 200 workgroups WITHOUT a K split for
                                                              // products with few 128-wide column tiles and a short K (force_cfg 64 only, see launch_epi)
@@ -265,6 +269,215 @@ __global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// ---- 8-phase schedule for the 256x256 tile (bf16 operands; the window-restart products, M = 1952 and 6561) ----------------------------
+// Wave (wr, wc) = (wave >> 2, wave & 3) owns 128 x 64 outputs = 4 x 2 accumulators of 32x32.  A K tile (64 of K) is consumed in four
+// phases, one 64 x 32 output quadrant each (8 MFMAs of 32x32x16 = 256 MFMA cycles):
+//   phase 1: read B sub0 (4 ds_read_b128) + A sub0 (8)   -> quadrant (A0, B0)
+//   phase 2: read B sub1 (4)                              -> (A0, B1)
+//   phase 3: read A sub1 (8, over the A0 registers)       -> (A1, B1)
+//   phase 4: no reads                                     -> (A1, B0)
+// and is staged as four HALF-TILES of 16 KiB: A-h{a} = the sub-a rows of both wave rows, B-h{b} = the sub-b columns of the four
+// wave columns -- so a half-tile is dead as soon as its phase has read it.  Two K tiles per iteration (even / odd buffer), every phase:
+//   { fragment reads ; ONE half-tile of LDS-DMA (2 x 1 KiB per wave) ; [counted waits] ; barrier ; lgkmcnt(0) ; MFMAs ; barrier }
+// DMA order (phase: half-tile):  1: odd.A-h1 (tile T+1) | 2: even.B-h0 (T+2) | 3: even.A-h0 | 4: even.B-h1 | 5: even.A-h1 |
+//                                6: odd.B-h0 (T+3) | 7: odd.A-h0 | 8: odd.B-h1
+//   WAR: a half-tile is re-staged two phases after the phase that read it, or one phase after when that phase retired the reads before
+//        its first barrier (the B sub0 reads of phases 1 / 5: issued first, s_waitcnt lgkmcnt(8) before the barrier).
+//   RAW: s_waitcnt vmcnt(6) at phases 4 and 8 only (three half-tiles stay in flight): phase 4's retires the four odd half-tiles (issued in
+//        phases 6, 7, 8, 1), read from phase 5 on; phase 8's the even ones (phases 2-5), read from phase 1 on -- always behind both barriers
+//        of the waiting phase, which also covers the other wave group.
+// The wave rows run the same program one barrier apart (waves 4-7 take one extra barrier first, waves 0-3 one last): the two waves of
+// a SIMD (w and w + 4) alternate between the read / DMA part and the MFMA part of a phase.
+// Tiles past the K range of the launch are staged from the last real tile (never read); the last iteration stages nothing and drains.
+template <typename C, bool M16, typename ACC>
+SVLN_DEV void p8_mainloop(const GemmArgs& p, char* smem, int row0, int col0, int st_begin, int n, int kchunks, int wave, int lane, ACC& acc) {
+    static_assert(C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4 && C::KG == 1 && C::ROWB == 128 && C::LDS_BYTES == 131072, "8-phase geometry");
+    constexpr int A_REG = 0, B_REG = 65536, BUFB = 32768;
+    const int wr = wave >> 2, wc = wave & 3, l8 = lane >> 3;
+    const int cj = (lane & 7) ^ (((wave * 8 + l8) >> 1) & 7);            // source chunk of this lane: the same for all eight pointers
+    const char* sA[2][2];
+    const char* sB[2][2];
+    int dA[2][2], dB[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rowA = j * 128 + a * 64 + wave * 8;
+            const int colB = ((wave >> 2) + 2 * j) * 64 + a * 32 + (wave & 3) * 8;
+            dA[a][j] = A_REG + rowA * 128;
+            dB[a][j] = B_REG + colB * 128;
+            sA[a][j] = (const char*)((const bf16*)p.A + (size_t)min(row0 + rowA + l8, p.M - 1) * p.lda) + cj * 16;
+            sB[a][j] = (const char*)((const bf16*)p.W + (size_t)min(col0 + colB + l8, p.N - 1) * p.ldw) + cj * 16;
+        }
+    auto issue = [&](auto KINDc, auto BUFc, int t) {                     // kind 0: A-h0, 1: A-h1, 2: B-h0, 3: B-h1
+        constexpr int kind = decltype(KINDc)::value, bufi = decltype(BUFc)::value;
+        const int st = st_begin + min(t, n - 1);
+        const bool full = (st + 1) * 8 <= kchunks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* g = (kind < 2 ? sA[kind & 1][j] : sB[kind & 1][j]) + (size_t)st * 128;
+            if (!full && st * 8 + cj >= kchunks) g = (const char*)p.zeros;
+            char* dst = smem + bufi * BUFB + (kind < 2 ? dA[kind & 1][j] : dB[kind & 1][j]);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+    // fragment read addresses.  32x32x16: lane (r32, h) reads row r32, chunk 2s + h of K step s (4 steps of 16); 16x16x32: lane (r16, g)
+    // reads row r16, chunk 4s + g of K step s (2 steps of 32).  Row blocks and sub-tiles are immediate offsets of the read.
+    constexpr int NS = M16 ? 2 : 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned aA[NS], aB[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int rr = M16 ? (lane & 15) : (lane & 31);
+        const int ch = M16 ? 4 * s + (lane >> 4) : 2 * s + (lane >> 5);
+        const unsigned sw = (unsigned)((ch ^ ((rr >> 1) & 7)) << 4);
+        aA[s] = lds0 + A_REG + (wr * 128 + rr) * 128 + sw;
+        aB[s] = lds0 + B_REG + (wc * 64 + rr) * 128 + sw;
+    }
+    u32x4 fa[8], fb[2][4];           // A sub: [row block][K step] (2 x 4 or 4 x 2); B sub0 / sub1: [column block][K step] (1 x 4 or 2 x 2)
+#define SVLN_P8_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    auto phase = [&](auto PHc, int T, bool last) {
+        constexpr int PH = decltype(PHc)::value, cur = PH >> 2, q = PH & 3, bo = cur * BUFB;
+        constexpr int ao = bo + (q == 2 ? 8192 : 0), bbo = bo + (q == 1 ? 4096 : 0), bs = q == 1 ? 1 : 0;
+        if constexpr (q == 0 || q == 1) {                                 // B sub0 / sub1
+            if constexpr (M16) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { SVLN_P8_READ(fb[bs][s], aB[s], bbo); SVLN_P8_READ(fb[bs][2 + s], aB[s], bbo + 2048); }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) SVLN_P8_READ(fb[bs][s], aB[s], bbo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (q == 0 || q == 2) {                                 // A sub0 / sub1
+            if constexpr (M16) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    SVLN_P8_READ(fa[s], aA[s], ao); SVLN_P8_READ(fa[2 + s], aA[s], ao + 2048);
+                    SVLN_P8_READ(fa[4 + s], aA[s], ao + 4096); SVLN_P8_READ(fa[6 + s], aA[s], ao + 6144);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { SVLN_P8_READ(fa[s], aA[s], ao); SVLN_P8_READ(fa[4 + s], aA[s], ao + 4096); }
+            }
+        }
+        if (!last) {
+            if constexpr (PH == 0) issue(I1{}, I1{}, T + 1);
+            if constexpr (PH == 1) issue(I2{}, I0{}, T + 2);
+            if constexpr (PH == 2) issue(I0{}, I0{}, T + 2);
+            if constexpr (PH == 3) issue(I3{}, I0{}, T + 2);
+            if constexpr (PH == 4) issue(I1{}, I0{}, T + 2);
+            if constexpr (PH == 5) issue(I2{}, I1{}, T + 3);
+            if constexpr (PH == 6) issue(I0{}, I1{}, T + 3);
+            if constexpr (PH == 7) issue(I3{}, I1{}, T + 3);
+        } else if constexpr (PH == 0) {
+            if (T + 1 < n) issue(I1{}, I1{}, T + 1);
+        }
+        if constexpr (q == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        if constexpr (q == 3) {
+            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if constexpr (q == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
+                         "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]));
+        else if constexpr (q == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
+        else if constexpr (q == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]));
+        constexpr int qa = q >> 1, qb = (q == 1 || q == 2) ? 1 : 0;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (M16) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+                        acc[4 * qa + ib][2 * qb + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[2 * ib + s]),
+                                                                                              __builtin_bit_cast(bf16x8, fb[qb][2 * jb + s]), acc[4 * qa + ib][2 * qb + jb], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    acc[2 * qa + ib][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[4 * ib + s]), __builtin_bit_cast(bf16x8, fb[qb][s]),
+                                                                                    acc[2 * qa + ib][qb], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    if (n <= 0) return;
+    // prologue: the even buffer (tile 0) and three half-tiles of the odd one, in the order the loop continues
+    issue(I2{}, I0{}, 0); issue(I0{}, I0{}, 0); issue(I3{}, I0{}, 0); issue(I1{}, I0{}, 0);
+    issue(I2{}, I1{}, 1); issue(I0{}, I1{}, 1); issue(I3{}, I1{}, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int T = 0; T < n; T += 2) {
+        const bool last = T + 2 >= n;
+        phase(std::integral_constant<int, 0>{}, T, last);
+        phase(std::integral_constant<int, 1>{}, T, last);
+        phase(std::integral_constant<int, 2>{}, T, last);
+        phase(std::integral_constant<int, 3>{}, T, last);
+        if (T + 1 >= n) break;
+        phase(std::integral_constant<int, 4>{}, T, last);
+        phase(std::integral_constant<int, 5>{}, T, last);
+        phase(std::integral_constant<int, 6>{}, T, last);
+        phase(std::integral_constant<int, 7>{}, T, last);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef SVLN_P8_READ
+}
+
+// epilogue of the 16x16x32 form (accumulator (mi, nj): rows mi * 16 + 4 * (lane >> 4) + e, column nj * 16 + (lane & 15) of the wave's
+// 128 x 64 tile): bias / activation / residual, or SwiGLU over the [gate 32 | up 32] column blocks (gate nj pairs with up nj + 2)
+template <typename T, int EPI>
+SVLN_DEV void p8_epilogue16(const GemmArgs& p, int row0, int col0, int wave, int lane, const f32x4 (&acc)[8][4]) {
+    const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, g = lane >> 4;
+    T* Cc = (T*)p.C;
+    const T* bias = (const T*)p.bias;
+    const T* res = (const T*)p.res;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int n_out = ((col0 + wc * 64) >> 1) + nj * 16 + r16;
+            const bool ok_n = (col0 + wc * 64 + 32 + nj * 16 + r16) < p.N;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = row0 + wr * 128 + mi * 16 + 4 * g + e;
+                    if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[mi][nj][e]) * acc[mi][nj + 2][e]);
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int nn = col0 + wc * 64 + nj * 16 + r16;
+        if (nn >= p.N) continue;
+        const float bv = bias ? to_f32(bias[nn]) : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = row0 + wr * 128 + mi * 16 + 4 * g + e;
+                if (m >= p.M) continue;
+                float v = epi_act<T, EPI>(acc[mi][nj][e] + bv);
+                if (res) {
+                    const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+                    v += to_f32(res[(size_t)rr * p.ldr + nn]);
+                }
+                Cc[(size_t)m * p.ldc + nn] = from_f32<T>(v);
+            }
+    }
+}
+
+
 // Same tiles and epilogues, operands staged with LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR or
 // ds_write hop).  One wave instruction fills 1 KiB of LDS = 8 consecutive 128-byte tile rows, lane l -> row l/8,
 // physical chunk l%8; the XOR swizzle is applied on the per-lane SOURCE address (the LDS image must stay lane-linear).
@@ -459,6 +672,21 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         }
     };
 
+    if constexpr (C::P8) {
+        static_assert(std::is_same<TA, bf16>::value && MI == 4 && NJ == 2 && !NTW && !SPLITK && !VP, "8-phase schedule: bf16 operands, 128 x 64 wave tiles, unsplit");
+        if constexpr (C::ILV) {                        // (the ILV flag of the 8-phase configurations selects the 32x32x16 form)
+            p8_mainloop<C, false>(p, smem, row0, col0, st_begin, n, kchunks, wave_all, lane, acc);
+        } else {
+            f32x4 acc16[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            p8_mainloop<C, true>(p, smem, row0, col0, st_begin, n, kchunks, wave_all, lane, acc16);
+            p8_epilogue16<T, EPI>(p, row0, col0, wave_all, lane, acc16);
+            return;
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) issue(st_begin + d, d);
@@ -471,6 +699,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         compute(buf, [&]() { if (i + D < n) issue(st_begin + i + D, nbuf); });
         buf = buf + 1 == C::NBUF ? 0 : buf + 1;
         nbuf = nbuf + 1 == C::NBUF ? 0 : nbuf + 1;
+    }
     }
     if constexpr (KG > 1) {
         // Exchange between the two K-groups: group g finishes accumulator rows i with i / (MI / KG) == g, so it hands the OTHER rows to its
@@ -994,7 +1223,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     //   M  > 256, >= 256 tiles of 128x128 (a full round at two workgroups per CU) -> 128x128 tiles, no split
     //   otherwise (less than a round of 128x128 tiles: every one-frame ViT product, o/down at T = 376) -> 256x128 tiles + split-K: inside the
     //   turn the K-split launch + reduce beats the half-empty unsplit launch (one-frame ViT fc1: 16.8 + 10.0 us against 31.4; qkv equal)
-    //   large M AND N (M > 512 and >= 256 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
+    //   large M AND N (M > 512 and >= 140 tiles of 256x256: window-restart gate/up, batched-env prefill, 9-frame ViT fc1/qkv) -> 256x256 tiles,
     //   wave tile 128x64: twice the MFMAs per stage and barrier of the 128x128 kernel.  With two row tiles (the 376-row first turn of an
     //   episode) the second one is mostly padding: 128x128 tiles take its gate/up from 192 to ~140 us (prefill of that turn 10.5 -> 9.0 ms)
     // M <= 32 (several envs decoded in lockstep): 32x128 tiles, 2 waves, three 20 KB stages in flight per workgroup and two
@@ -1016,9 +1245,22 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         return launch_split<T, EPI, CfgSkinny>(s, a, S);
     }
     const int tilesbig = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if ((tilesbig >= 256 && a.M > 512 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
+    // (>= 140 tiles: the T = 1952 qkv product, 8 x 18 tiles on 256 CUs, runs 85 us on 256x256 tiles against 101 on 576 tiles of 128x128;
+    //  o / down at 112 tiles stay on 128x128: 375 against 308 us for down)
+    if ((tilesbig >= 140 && a.M > 512 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
         a.nsplit = 1;
         a.launch_tiles = tilesbig;
+        if constexpr (std::is_same<T, bf16>::value) {
+            // 8-phase schedule with 16x16x32 MFMAs (bf16 operands).  Measured inside the turn (tools/ab_lib.sh, three alternating rounds):
+            // window-restart turn 55.2 ms with the stage ring, 55.5 with the 8-phase schedule on 32x32x16 MFMAs, 52.3 with it on
+            // 16x16x32 -- the schedule alone is worth nothing here (the tile is bound by the CU's staging rate), the MFMA shape is: the
+            // chip holds a higher clock on it under sustained load.  force_cfg 256 | 0x4000 = stage ring, | 0x8000 = 32x32x16 form (tests)
+            if (!a.a_scale && a.zeros && !(a.force_cfg & 0x4000)) {
+                if (a.force_cfg & 0x8000) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, Cfg8P32, false>), dim3(tilesbig), dim3(Cfg8P32::THREADS), Cfg8P32::LDS_BYTES, s, a);
+                else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, Cfg8P, false>), dim3(tilesbig), dim3(Cfg8P::THREADS), Cfg8P::LDS_BYTES, s, a);
+                return false;
+            }
+        }
         launch_cfg<T, EPI, CfgBig, false>(s, a, 1);
         return false;
     }
@@ -1149,6 +1391,8 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128K2, false>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
     if constexpr (EPI == EPI_NONE) set_max_lds((const void*)gemm_glds_kernel<T, EPI_NONE, Cfg128K2, false, T, false, true>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
+    if constexpr (std::is_same<T, bf16>::value) set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg8P, false>, Cfg8P::LDS_BYTES, Cfg8P::THREADS);
+    if constexpr (std::is_same<T, bf16>::value) set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg8P32, false>, Cfg8P32::LDS_BYTES, Cfg8P32::THREADS);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false, fp8_t>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);

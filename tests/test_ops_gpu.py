@@ -32,7 +32,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -109,6 +109,54 @@ def test_gemm_fused_norm(dtype, M, N, K, split, kind, expect_fused):
         assert_close(xn, exp_norm, dtype, f"fused {kind} norm {M}x{N}x{K}")
     else:
         assert float(xn.float().min()) == 7.0 and float(xn.float().max()) == 7.0
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (1952, 1024, 3584, _lib.EPI_NONE),         # window-restart rows (7.6 row tiles), 56 K tiles
+    (700, 768, 192, _lib.EPI_NONE),            # 3 K tiles (odd: the second half of the last iteration is skipped)
+    (513, 512, 320, _lib.EPI_GELU_TANH),       # 5 K tiles
+    (300, 300, 64, _lib.EPI_NONE),             # one K tile; ragged M and N
+    (729, 1152, 4304, _lib.EPI_NONE),          # 67.25 K tiles: ragged last tile
+    (1000, 640, 128, _lib.EPI_NONE),           # two K tiles: prologue only
+    (1952, 2048, 1024, _lib.EPI_SWIGLU),       # gate/up epilogue
+])
+def test_gemm_8phase_equals_stage_ring(M, N, K, epi):
+    """The 8-phase schedule of the 256x256 tile (gemm.hip: p8_mainloop).  Its 32x32x16 form (force_cfg 256 | 0x8000) accumulates every output
+    over K in the same order as the stage-ring kernel of the same tile (256 | 0x4000), so the two must agree BIT FOR BIT; the shipping
+    16x16x32 form (256) sums K in groups of 32, so it is held to the fp32 product within the bf16 bound -- and to ITSELF bit for bit over
+    repeated launches: a race in the half-tile staging (a read before its DMA landed, a re-stage before the last read) shows as a tile
+    that differs between launches on the same operands."""
+    m = engine(TINY, torch.bfloat16)
+    A = q(rnd((M, K), 71), torch.bfloat16).to(torch.bfloat16).cuda()
+    W = q(rnd((N, K), 72, 1.0 / math.sqrt(K)), torch.bfloat16).to(torch.bfloat16).cuda()
+    b = q(rnd((N,), 73, 0.1), torch.bfloat16).to(torch.bfloat16).cuda()
+    n_out = N // 2 if epi == _lib.EPI_SWIGLU else N
+    bias = None if epi == _lib.EPI_SWIGLU else ptr(b)
+
+    def run(cfg, fill):
+        out = torch.full((M, n_out), fill, dtype=torch.bfloat16, device="cuda")
+        torch.cuda.synchronize()
+        chk(m._lib.svln_op_gemm(m._h, ptr(A), K, ptr(W), K, ptr(out), n_out, bias, None, 0, 0, M, N, K, epi, cfg, 0))
+        torch.cuda.synchronize()
+        return out
+
+    ring = run(256 | 0x4000, 0.0)
+    if epi == _lib.EPI_SWIGLU:                   # (the gate / up packing itself is covered by test_gemm_swiglu_and_posmod)
+        acc = A.float().cpu() @ W.float().cpu().t()
+        acc = acc.view(M, N // 64, 2, 32)
+        exp = (O.silu(acc[:, :, 0]) * acc[:, :, 1]).reshape(M, n_out)
+    else:
+        exp = A.float().cpu() @ W.float().cpu().t() + b.float().cpu()
+        if epi == _lib.EPI_GELU_TANH:
+            exp = O.gelu_tanh(exp)
+    assert_close(ring, exp, torch.bfloat16, f"stage ring {M}x{N}x{K}")
+    first16 = run(256, 5.0)
+    assert_close(first16, exp, torch.bfloat16, f"8-phase 16x16x32 {M}x{N}x{K}")
+    for rep in range(10):
+        out = run(256 | 0x8000, 3.0)
+        assert torch.equal(out.view(torch.int16), ring.view(torch.int16)), ("32x32x16 form", rep, int((out.view(torch.int16) != ring.view(torch.int16)).sum()))
+        out = run(256, 3.0)
+        assert torch.equal(out.view(torch.int16), first16.view(torch.int16)), ("16x16x32 form", rep, int((out.view(torch.int16) != first16.view(torch.int16)).sum()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,5 +1,5 @@
 # Where a GEMM product spends its cycles: memory-path counters of the main gemm_glds launch (one kbench run per counter group; rocprofv3
-# --pmc alone, as the pool requires).  bash tools/pmc_diag.sh "<M,N,K,epi,force_cfg,force_split>" [...]   -> gpurun_out/pmc_diag.txt
+# --pmc alone, as the pool requires; the TA / TD counter groups hang the profiler on this pool and are left out).  bash tools/pmc_diag.sh "<M,N,K,epi,force_cfg,force_split>" [...]   -> gpurun_out/pmc_diag.txt
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_diag
 rm -rf $OUT && mkdir -p $OUT
@@ -12,8 +12,6 @@ CGRP=(
  "TCP_TOTAL_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN1_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"
  "TCC_EA0_RDREQ_LEVEL_sum TCC_CYCLE_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum"
- "TA_BUSY_avr TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
- "TD_TD_BUSY_sum TD_TC_STALL_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
 )
 : > $GRAFT_REPO_ROOT/gpurun_out/pmc_diag.txt
 for SH in "$@"; do
