@@ -673,7 +673,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     };
 
     if constexpr (C::P8) {
-        static_assert(std::is_same<TA, bf16>::value && MI == 4 && NJ == 2 && !NTW && !SPLITK && !VP, "8-phase schedule: bf16 operands, 128 x 64 wave tiles, unsplit");
+        static_assert(std::is_same<TA, bf16>::value && MI == 4 && NJ == 2 && !NTW && !VP && (!SPLITK || !C::ILV), "8-phase schedule: bf16 operands, 128 x 64 wave tiles");
         if constexpr (C::ILV) {                        // (the ILV flag of the 8-phase configurations selects the 32x32x16 form)
             p8_mainloop<C, false>(p, smem, row0, col0, st_begin, n, kchunks, wave_all, lane, acc);
         } else {
@@ -683,7 +683,24 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             p8_mainloop<C, true>(p, smem, row0, col0, st_begin, n, kchunks, wave_all, lane, acc16);
-            p8_epilogue16<T, EPI>(p, row0, col0, wave_all, lane, acc16);
+            if constexpr (SPLITK) {                    // fp32 partials of this K slice; the reduce kernels apply the epilogue
+                float* slab = p.ws + (size_t)ks * p.M * p.N;
+                const int r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const int nn = col0 + wc * 64 + nj * 16 + r16;
+                    if (nn >= p.N) continue;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int m = row0 + wr * 128 + mi * 16 + 4 * g4 + e;
+                            if (m < p.M) slab[(size_t)m * p.N + nn] = acc16[mi][nj][e];
+                        }
+                }
+            } else {
+                p8_epilogue16<T, EPI>(p, row0, col0, wave_all, lane, acc16);
+            }
             return;
         }
     } else {
@@ -1179,10 +1196,15 @@ template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStrea
     hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
 }
 
+// sum the split-K slabs and apply the epilogue (returns true when the reduce also emitted the following norm / the fused tail)
+template <typename T, int EPI> bool launch_reduce(hipStream_t s, const GemmArgs& a);
 template <typename T, int EPI, typename C = Cfg256> bool launch_split(hipStream_t s, GemmArgs a, int S) {
-    static_assert(C::BN == Cfg256::BN, "the slab reduce assumes 128-column tiles");
+    static_assert(C::BN == Cfg256::BN, "tail launches (tile_base > 0) assume 128-column tiles");
     a.nsplit = S;
     launch_cfg<T, EPI, C, true>(s, a, S);
+    return launch_reduce<T, EPI>(s, a);
+}
+template <typename T, int EPI> bool launch_reduce(hipStream_t s, const GemmArgs& a) {
     if (EPI == EPI_NONE && a.norm_out && a.norm_w && a.tile_base == 0 && a.N <= 4096 && a.N % 4 == 0) {
         hipLaunchKernelGGL((splitk_rownorm_kernel<T>), dim3(a.M), dim3(((a.N / 4 + 63) / 64) * 64), 0, s, a);
         return true;
@@ -1247,6 +1269,19 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     const int tilesbig = ((a.M + 255) / 256) * ((a.N + 255) / 256);
     // (>= 140 tiles: the T = 1952 qkv product, 8 x 18 tiles on 256 CUs, runs 85 us on 256x256 tiles against 101 on 576 tiles of 128x128;
     //  o / down at 112 tiles stay on 128x128: 375 against 308 us for down)
+    // Long-K products with fewer 256x256 tiles than CUs (down_proj at T = 1952: 8 x 14 tiles, 296 K tiles): two K slices per tile on the
+    // 8-phase kernel + the slab reduce (which also emits the following RMSNorm) instead of 448 tiles of 128x128
+    if constexpr (std::is_same<T, bf16>::value) {
+        const int ktiles = (a.K / EPC + 7) / 8;
+        const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0) && (size_t)2 * a.M * a.N <= a.ws_elems;
+        if (((tilesbig >= 96 && tilesbig <= 128 && a.M > 512 && ktiles >= 128 && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 258) &&
+            a.zeros && !a.a_scale && can_split) {
+            a.nsplit = 2;
+            a.launch_tiles = tilesbig;
+            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, Cfg8P, true>), dim3(tilesbig * 2), dim3(Cfg8P::THREADS), Cfg8P::LDS_BYTES, s, a);
+            return launch_reduce<T, EPI>(s, a);
+        }
+    }
     if ((tilesbig >= 140 && a.M > 512 && a.zeros && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 256) {
         a.nsplit = 1;
         a.launch_tiles = tilesbig;
@@ -1392,6 +1427,7 @@ template <typename T, int EPI> static void gemm_attr() {
     if constexpr (EPI == EPI_NONE) set_max_lds((const void*)gemm_glds_kernel<T, EPI_NONE, Cfg128K2, false, T, false, true>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgBig, false>, CfgBig::NBUF * CfgBig::STAGE_BYTES, CfgBig::THREADS);
     if constexpr (std::is_same<T, bf16>::value) set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg8P, false>, Cfg8P::LDS_BYTES, Cfg8P::THREADS);
+    if constexpr (std::is_same<T, bf16>::value) set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg8P, true>, Cfg8P::LDS_BYTES, Cfg8P::THREADS);
     if constexpr (std::is_same<T, bf16>::value) set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg8P32, false>, Cfg8P32::LDS_BYTES, Cfg8P32::THREADS);
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false, fp8_t>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);

@@ -32,7 +32,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (258, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 258 = 256x256 tiles, two K slices on the 8-phase kernel; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -79,11 +79,14 @@ def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     (729, 1152, 1152, 9, "ln", True),       # ... also with a forced split count
     (729, 1152, 4304, 8, "ln", True),       # SigLIP fc2 -> next layer_norm1
     (50, 144, 288, 2, "ln", True),
+    (1952, 3584, 8192, 0, "rms", "bf16"),   # down_proj-like at the window-restart rows: 8 x 14 tiles of 256x256, two K slices on the 8-phase kernel
 ])
 def test_gemm_fused_norm(dtype, M, N, K, split, kind, expect_fused):
     """o_proj / down_proj (+ residual) with the following RMSNorm, and SigLIP out_proj / fc2 (+ bias + residual) with the following
     LayerNorm, emitted by the split-K reduce (modeling_qwen2.py:269-299, siglip_encoder.py:269-305)."""
     import ctypes as C
+    if expect_fused == "bf16":                          # (the 8-phase kernel takes bf16 operands: the fp32 engine runs this product unsplit)
+        expect_fused = dtype == torch.bfloat16
     m = engine(TINY, dtype)
     ln = kind == "ln"
     A, Wt = q(rnd((M, K), 11), dtype), q(rnd((N, K), 12, 1.0 / math.sqrt(K)), dtype)
