@@ -516,9 +516,14 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int bm = bid % tiles_m;
+    // Workgroup order (after the XCD remap consecutive ids share an XCD and its L2): row tiles fastest -- neighbours share the WEIGHT tile,
+    // the activations stream through (the LLM products: weights >> activations); bn_fast: column tiles fastest -- neighbours share the
+    // ACTIVATION rows (the nine-frame ViT products: 6561 rows against 1152-4304 columns; fc2 reads 56 MB of activations, 10 MB of weights)
+    const int tiles_n_l = p.launch_tiles / tiles_m;
+    const bool bnf = !SPLITK && p.bn_fast;
+    const int bm = bnf ? bid / tiles_n_l : bid % tiles_m;
     const int ks = (bid / tiles_m) % nsplit;
-    const int bn = p.tile_base + bid / (tiles_m * nsplit);
+    const int bn = p.tile_base + (bnf ? bid % tiles_n_l : bid / (tiles_m * nsplit));
     const int row0 = bm * C::BM, col0 = bn * C::BN;
     const int kchunks = p.K / EPC;
     const int stages_total = (kchunks + C::CH - 1) / C::CH;
@@ -1232,6 +1237,10 @@ template <typename T, int EPI> bool launch_reduce(hipStream_t s, const GemmArgs&
 template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if (a.M <= 0 || a.N <= 0) return false;
     a.vp_on = 0;
+    // Column tiles fastest when the activations are the big operand AND larger than the L2s together (32 MB): the nine-frame ViT fc2
+    // (6561 x 4304 activations = 56 MB against 10 MB of weights) 95 -> 85 us; the other nine-frame products (15 MB of activations) measured
+    // 1-4 % slower that way and keep the row-tiles-fastest order.  force_cfg | 0x1000 = row tiles fastest, | 0x10000 = column tiles fastest (tests)
+    a.bn_fast = (((size_t)a.M * a.K * sizeof(T) > ((size_t)32 << 20) && a.M > a.N && !(a.force_cfg & 0x1000)) || (a.force_cfg & 0x10000)) ? 1 : 0;
     a.nt_w = a.M <= 256 ? 1 : 0;          // the heuristics below give such products ONE row tile (256x128 or 32x128 tiles)
     const int EPC = a.a_scale ? 16 : Elt<T>::PER_CHUNK;      // 16-byte chunks of K: e4m3 operands hold 16 values per chunk
     a.tile_base = 0;
@@ -1389,7 +1398,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
 // lm_head of <= 32 rows (envs decoded together) with the arg-max in the epilogue: one pass of 32x128 tiles over the vocabulary, the weight
 // tile staged non-temporally, no C.  Returns the number of column tiles (= partials per row).
 template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a) {
-    a.nt_w = 1; a.tile_base = 0; a.nsplit = 1; a.vp_on = 0;
+    a.nt_w = 1; a.tile_base = 0; a.nsplit = 1; a.vp_on = 0; a.bn_fast = 0;
     a.launch_tiles = (a.N + 127) / 128;
     hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
     return a.launch_tiles;

@@ -28,6 +28,7 @@ struct GemmArgs {
     float* ws; size_t ws_elems;   // split-K slab workspace (fp32) or null
     int nsplit, tile_base, launch_tiles;   // filled by the launcher (K splits; first column tile and tile count of this launch)
     int nt_w;                              // filled by the launcher: stage the weight tile with non-temporal loads (weights read once)
+    int bn_fast;                           // filled by the launcher: consecutive workgroups walk the COLUMN tiles of one row tile (activations larger than weights)
     const void* zeros;            // >= 16 B of zeros in device memory (K-tail source of the LDS-DMA path); null -> register-staged kernel
     // optional fused RMSNorm of the finished output rows (o_proj -> post_attention_layernorm, down_proj -> next input_layernorm):
     // when the product takes the split-K path with N <= 4096 the slab reduce also writes norm_out = rmsnorm(C) * norm_w and

@@ -32,7 +32,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (258, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 258 = 256x256 tiles, two K slices on the 8-phase kernel; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (258, 0), (0x10000, 0), (128 | 0x10000, 0), (256 | 0x10000, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 258 = 256x256 tiles, two K slices on the 8-phase kernel; | 0x10000 = column tiles fastest in the workgroup order; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual
@@ -41,6 +41,7 @@ def chk(rc):
     (64, 256, 592, _lib.EPI_GELU_ERF, True, False),      # patch-embed K
     (1, 128, 64, _lib.EPI_NONE, False, False),           # degenerate
     (729, 1152, 1152, _lib.EPI_NONE, True, True),        # ViT out_proj at one frame
+    (1300, 384, 320, _lib.EPI_NONE, True, True),         # more rows than columns, several row tiles: column tiles fastest in the workgroup order
 ])
 def test_gemm(dtype, M, N, K, epi, bias, res, cfgsplit):
     if cfgsplit[0] == 32 and M > 32:
