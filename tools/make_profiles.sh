@@ -1,8 +1,8 @@
-# One GPU-box call that regenerates the round's committed profile artefacts under gpurun_out/r02/ (copy into profiles/ afterwards):
+# One GPU-box call that regenerates the round's committed profile artefacts under gpurun_out/<round>/ (copy into profiles/ afterwards):
 #   bench plain (incl. the measured CPU baseline), bench under rocprofv3 --kernel-trace --stats, by-shape + per-phase summaries,
 #   and the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, as the microarch guide prescribes) of the roofline kernel.
 set -e
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

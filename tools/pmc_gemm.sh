@@ -3,7 +3,7 @@
 #   pass 2  rocprofv3 --pmc <SQ / GRBM counters> -> MFMA-busy cycles, wave-cycle split
 # writes gpurun_out/<round>_gemm_mfma_pmc.json  (copy into profiles/)
 set -e
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_gemm
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
