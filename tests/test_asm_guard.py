@@ -1,4 +1,9 @@
-"""Build-time guard for the inline-asm LDS reads of the attention kernels.
+"""Build-time guards on the generated gfx950 assembly (hipcc cross-compiles without a GPU).
+
+1. The inline-asm LDS reads of the attention kernels, below.
+2. The 8-phase GEMM schedule (gemm.hip: p8_mainloop), at the end of this file: its synchronisation is placed by COUNT (half-tiles of
+   LDS-DMA in flight behind `s_waitcnt vmcnt(6)`, fragment reads behind `lgkmcnt`), so the test pins the counts the derivation assumes.
+
 
 attention.hip issues the Vt fragment reads as `asm volatile("ds_read_b64 %0, ...")` with an "=v" output and retires them later with a
 separate asm `s_waitcnt lgkmcnt(N)` naming the destinations.  hipcc does not know the read is still in flight: if register allocation
@@ -105,3 +110,49 @@ def test_attention_asm_lds_reads_are_not_touched_before_their_wait():
         spill = [ln for ln in lines if "scratch_" in ln or "buffer_store_dword" in ln and "offen" in ln]
         assert not spill, (name, spill[:3])            # no scratch traffic in the attention kernels
     assert total >= 32                                  # the bf16 instantiations carry the asm reads
+
+
+GEMM_SRC = os.path.join(ROOT, "streamvln_amd", "csrc", "gemm.hip")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_gemm_8phase_loop_has_the_instruction_counts_its_waits_assume():
+    """p8_mainloop orders LDS-DMA against the fragment reads with COUNTED waits: per wave two DMA instructions per phase, `vmcnt(6)` at
+    phases 4 and 8 (three half-tiles stay in flight), 12 / 4 / 8 / 0 asm `ds_read_b128` per phase with `lgkmcnt(8)` retiring the four B reads
+    of phases 1 and 5 before the barrier.  A compiler that adds, merges or re-times any of these silently breaks the derivation, so the
+    generated code of every 8-phase instantiation is checked: no scratch, <= 256 VGPRs (two waves per SIMD), 48 fragment reads, 19 barriers
+    (1 + the stagger + 16 + the closing one), the MFMA count of the form, two `lgkmcnt(8)`, 30-32 DMA instructions, and 6 and 0 as the only
+    `vmcnt` immediates (hipcc adds no drain of its own in front of the asm fragment reads)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "gemm.s")
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S", "-o", out, GEMM_SRC],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(out).read().splitlines()
+    funcs, cur = {}, None
+    for ln in text:
+        m = re.match(r"^(_ZN\S*gemm_glds_kernel\S*TileCfgILi256ELi256ELi2ELi4ELi128ELb0ELi2ELb[01]ELi1ELb1EEE\S*):", ln)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append(ln)
+            if ln.startswith("\t.end_amdhsa_kernel"):
+                cur = None
+    assert len(funcs) >= 12, list(funcs)                      # 4 epilogues x (16x16x32, its two-slice form, 32x32x16)
+    for name, lines in funcs.items():
+        code = [ln.split(";")[0].strip() for ln in lines]
+        code = [c for c in code if c and not c.startswith(".") and not c.endswith(":")]
+        form32 = "ELb1ELi1ELb1EEE" in name                     # TileCfg<..., ILV = true, 1, P8 = true> = the 32x32x16 form
+        meta = "\n".join(lines)
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta), name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, name
+        assert not [c for c in code if c.startswith("scratch_")], name
+        n_mfma = len([c for c in code if c.startswith("v_mfma_f32_32x32x16_bf16" if form32 else "v_mfma_f32_16x16x32_bf16")])
+        assert n_mfma == (64 if form32 else 128), (name, n_mfma)
+        assert len([c for c in code if c.startswith("ds_read_b128")]) == 48, name
+        assert len([c for c in code if c.startswith("s_barrier")]) == 19, name
+        vm = [int(x) for c in code for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", c)]
+        assert set(vm) <= {0, 6} and vm.count(6) >= 3, (name, vm)
+        assert len([c for c in code if c.startswith("s_waitcnt lgkmcnt(8)")]) == 2, name
+        assert 30 <= len([c for c in code if c.startswith("global_load_lds_dwordx4")]) <= 32, name
