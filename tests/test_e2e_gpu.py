@@ -99,6 +99,24 @@ BF16_HIDDEN_REL = {"tiny_episode": 1.2e-2, "true1_episode": 8e-3, "true4_episode
 BF16_MARGIN = 0.05
 
 
+def test_bf16_episode_through_the_restart_is_bit_reproducible():
+    """true1_episode twice on one bf16 engine: first turn, seven steady turns and the window restart (9-frame ViT batch, T = 1952 prefill on
+    the 8-phase GEMM with its counted LDS-DMA waits, the two-slice down_proj, the column-tiles-fastest fc2).  No kernel on the path uses
+    atomics or an order-dependent reduction, so ids and final-norm hidden rows must repeat BIT FOR BIT; a staging race under the real
+    load of a turn (which an isolated op test may not provoke) would show here as a differing row."""
+    sc = SCENARIOS["true1_episode"]
+    m = _model(sc, torch.bfloat16)
+    log_a, taps_a = _run(m, sc)
+    m.reset(1)
+    log_b, taps_b = _run(m, sc)
+    assert len(log_a) == len(log_b) == 9
+    for t, (a, b) in enumerate(zip(log_a, log_b)):
+        assert a["out"].sequences[0].tolist() == b["out"].sequences[0].tolist(), t
+    for t, (a, b) in enumerate(zip(taps_a, taps_b)):
+        assert a["cache_len"] == b["cache_len"] and np.array_equal(a["hidden"], b["hidden"]), t
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["tiny_episode", "true1_episode", "true4_episode"])
 def test_bf16_mode_vs_golden(name):
     sc, g = SCENARIOS[name], load_golden(name)

@@ -2,6 +2,7 @@
 seeded inputs, in both engine dtypes (fp32 parity mode: tight; bf16 shipping mode: bf16-rounding bound)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -156,7 +157,7 @@ def test_gemm_8phase_equals_stage_ring(M, N, K, epi):
     assert_close(ring, exp, torch.bfloat16, f"stage ring {M}x{N}x{K}")
     first16 = run(256, 5.0)
     assert_close(first16, exp, torch.bfloat16, f"8-phase 16x16x32 {M}x{N}x{K}")
-    for rep in range(10):
+    for rep in range(int(os.environ.get("SVLN_RACE_REPS", "10"))):         # (SVLN_RACE_REPS=400 for a long race screen of a schedule edit)
         out = run(256 | 0x8000, 3.0)
         assert torch.equal(out.view(torch.int16), ring.view(torch.int16)), ("32x32x16 form", rep, int((out.view(torch.int16) != ring.view(torch.int16)).sum()))
         out = run(256, 3.0)
