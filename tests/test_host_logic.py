@@ -192,6 +192,37 @@ def test_qwen_prompt_encoder_follows_preprocess_qwen():
     assert ag.model.calls[0]["inputs"].shape[1] == len(enc(True, False, "go left"))
 
 
+def test_eval_flavour_prompts_equal_the_reference_eval_loop():
+    """tests/golden/eval_prompts.npz = what the REFERENCE's Habitat loop assembles and tokenises for the three situations of a window
+    (oracle/make_eval_prompts.py: the `if output_ids is None` statement of `VLNEvaluator.eval_action`, streamvln_eval.py:291-302, executed
+    as it stands, then the reference's `preprocess_qwen` :393-469 under `random.seed(k)` with the stub tokenizer).
+    QwenPromptEncoder(flavour="eval") must produce the same text and the same ids -- including WHICH conjunction `random.choice` picks
+    for a given seed, the "These are your historical observations <memory>." sentence and the system turn only when the reference adds it."""
+    import random
+    from stub_tokenizer import StubTokenizer                   # the deterministic tokenizer the fixture was generated with
+    from streamvln_amd.agent import CONJUNCTIONS
+    from streamvln_amd.prompt import QwenPromptEncoder
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_prompts.npz"))
+    assert list(g["conjunctions"]) == list(CONJUNCTIONS)
+    instruction = str(g["instruction"])
+    picked = set()
+    for name, first_turn, with_memory in (("first", True, False), ("memory", True, True), ("later", False, False)):
+        for seed in g["seeds"].tolist():
+            enc = QwenPromptEncoder(StubTokenizer(), flavour="eval", rng=random.Random(seed))
+            key = f"{name}_s{seed}"
+            gold = g[key + "_ids"].tolist()
+            assert bool(g[key + "_add_system"]) == first_turn
+            if first_turn:
+                assert enc.first_turn_text(with_memory, instruction) == str(g[key + "_text"])
+            else:
+                assert str(g[key + "_text"]) == ""
+            ids = enc(first_turn, with_memory, instruction)
+            assert ids == gold, (key, ids, gold)
+            assert gold.count(MEMORY_TOKEN_INDEX) == int(with_memory) and gold.count(IMAGE_TOKEN_INDEX) == 1
+            picked.add(tuple(gold[-12:]))
+    assert len(picked) >= 3                                    # the seeds really select different conjunctions
+
+
 def test_config_from_hf_checkpoint_config():
     """config.json / AutoConfig of a StreamVLN checkpoint -> StreamVLNConfig (streamvln_eval.py:521-527); unsupported structure raises."""
     from types import SimpleNamespace
