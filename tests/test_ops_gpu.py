@@ -124,6 +124,7 @@ def test_gemm_fused_norm(dtype, M, N, K, split, kind, expect_fused):
     (729, 1152, 4304, _lib.EPI_NONE),          # 67.25 K tiles: ragged last tile
     (1000, 640, 128, _lib.EPI_NONE),           # two K tiles: prologue only
     (1952, 2048, 1024, _lib.EPI_SWIGLU),       # gate/up epilogue
+    (6561, 3456, 1152, _lib.EPI_NONE),         # nine-frame ViT qkv: 26 x 14 tiles, the last column tile half empty, 18 K tiles
 ])
 def test_gemm_8phase_equals_stage_ring(M, N, K, epi):
     """The 8-phase schedule of the 256x256 tile (gemm.hip: p8_mainloop).  Its 32x32x16 form (force_cfg 256 | 0x8000) accumulates every output
