@@ -270,8 +270,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // ---- 8-phase schedule for the 256x256 tile (bf16 operands; the window-restart products, M = 1952 and 6561) ----------------------------
-// Wave (wr, wc) = (wave >> 2, wave & 3) owns 128 x 64 outputs = 4 x 2 accumulators of 32x32.  A K tile (64 of K) is consumed in four
-// phases, one 64 x 32 output quadrant each (8 MFMAs of 32x32x16 = 256 MFMA cycles):
+// Wave (wr, wc) = (wave >> 2, wave & 3) owns 128 x 64 outputs: 8 x 4 accumulators of 16x16 (M16, the shipping form: v_mfma_f32_16x16x32_bf16
+// holds a higher clock under the sustained load of these products) or 4 x 2 of 32x32 (the form that is bit-identical to the stage ring,
+// kept for the tests).  A K tile (64 of K) is consumed in four phases, one 64 x 32 output quadrant each (16 MFMAs of 16x16x32 or 8 of
+// 32x32x16 = 256 MFMA cycles; the fragment-read counts are the same for both forms):
 //   phase 1: read B sub0 (4 ds_read_b128) + A sub0 (8)   -> quadrant (A0, B0)
 //   phase 2: read B sub1 (4)                              -> (A0, B1)
 //   phase 3: read A sub1 (8, over the A0 registers)       -> (A1, B1)
