@@ -127,6 +127,16 @@ int svln_get_hidden(svln_engine* h, float* host_out, int max_rows, int32_t* n_ro
 int svln_get_embeds(svln_engine* h, int env, int start_row, int n_rows, float* host_out);
 int svln_get_frame_feats(svln_engine* h, int start_row, int n_rows, float* host_out);
 int svln_get_top2(svln_engine* h, float* host_out2);
+/* prefill taps of svln_generate (single env): enable != 0 records the LAST row of the residual stream after every decoder layer of the
+ * next prefills (svln_get_layer_taps: host_out [layers][hidden]); probe_layer >= 0 additionally records, for every row of the prefill,
+ * the operands the products of that one layer actually saw (svln_get_layer_probe, which: 0 = x entering the layer, 1 = x leaving it,
+ * 2 = attention output [q_heads * 128], 3 = x after the attention residual, 4 = post_attention_layernorm(x), 5 = silu(gate) * up
+ * [inter], 6 = input_layernorm(x), 7 = the q | k | v rows after bias and RoPE [(q_heads + 2 kv_heads) * 128]; the others [hidden]),
+ * so that each fused stage can be checked against the oracle on the engine's own inputs, at its own scale.  enable = 0 switches
+ * both off. */
+int svln_set_layer_taps(svln_engine* h, int enable, int probe_layer);
+int svln_get_layer_taps(svln_engine* h, float* host_out);
+int svln_get_layer_probe(svln_engine* h, int which, float* host_out, int64_t max_elems, int32_t* n_rows, int32_t* n_cols);
 
 /* -- decode execution mode + timing probes (bench.py) */
 int svln_set_decode_graph(svln_engine* h, int enable);     /* replay the per-token decode step as a hipGraph */

@@ -30,6 +30,11 @@ writes `tests/golden/*.npz`.  The reference has no tests or fixtures of its own
 
 All arithmetic is fp32 on the CPU via torch tensor ops (matmul / exp / erf / tanh); no
 nn.Module of transformers or of the reference is used here.
+
+Quantisation-emulating modes (`Fp8Emu`; round 4): NO REFERENCE COUNTERPART -- the reference is bf16 only
+(streamvln_eval.py:526).  They restate the numeric scheme of the engine's opt-in e4m3 modes (svln_set_fp8_decode /
+svln_set_fp8_gemm: per-row scales amax / 448, round-to-nearest-even OCP e4m3, fp32 accumulate) so that the HIP fp8 kernels are
+compared with the SAME scheme instead of with bf16; parity of these modes is therefore pinned by this project only.
 """
 from __future__ import annotations
 
@@ -87,6 +92,64 @@ def rms_norm(x, g, eps):    # Qwen2RMSNorm (modeling_qwen2.py:238-252)
 def linear(x, w, b=None):
     y = x @ w.t()
     return y if b is None else y + b
+
+
+# ----------------------------------------------------------------------------- opt-in e4m3 modes (no reference counterpart)
+def qdq_e4m3_rows(x: torch.Tensor) -> torch.Tensor:
+    """Per-row e4m3 quantise -> dequantise, the arithmetic of gemv.hip `quant_fp8_rows_kernel`: scale = amax / 448 (1 for an all-zero
+    row), q = e4m3_rne(clamp(x * (1 / scale), +-448)), value = q * scale.  fp32 in, fp32 out."""
+    amax = x.abs().amax(-1, keepdim=True)
+    sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    inv = 1.0 / sc
+    q = (x * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+    return q * sc
+
+
+class Fp8Emu:
+    """The engine's two opt-in e4m3 modes as a CPU restatement (extension, no reference counterpart):
+      decode  (svln_set_fp8_decode): the single-token decode step's four projections and EVERY lm_head product read per-row e4m3
+              copies of the weights; activations stay in the engine dtype (weight-only, "w8").
+      gemm    (svln_set_fp8_gemm): the multi-row (prefill) products q/k/v, o, gate/up, down multiply per-row e4m3 activations with
+              the same e4m3 weight copies ("w8a8"); bias / residual / norms / attention / lm_head are not quantised.
+    act_dtype: the engine rounds activations to its storage type before they are quantised (bf16: the modes exist on bf16 engines
+    only); None keeps fp32.
+    store_dtype (default None = fp32 throughout): round every tensor the engine STORES between kernels to this type as well (norm
+    outputs, q / k / v before and after RoPE, the attention output, the residual stream after each residual add, the SwiGLU product) --
+    the unfused kernel sequence of a prefill with more than 256 rows.  An activation quantiser turns a bf16-sized difference delta of
+    its input into sqrt(delta * step) (a fraction delta / step of the elements moves by a whole e4m3 step), so an fp32-storage
+    emulation sits 2-4 % of a layer's contribution away from the bf16 engine for that reason alone; with the storage rounding restated
+    the comparison is sharp again (tests/test_fp8_gpu.py, teacher-forced layers)."""
+
+    LINEARS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+               "mlp.down_proj")
+
+    def __init__(self, decode: bool = False, gemm: bool = False, act_dtype: Optional[torch.dtype] = torch.bfloat16,
+                 store_dtype: Optional[torch.dtype] = None):
+        self.decode, self.gemm, self.act_dtype, self.store_dtype = bool(decode), bool(gemm), act_dtype, store_dtype
+        self._dq: Dict[str, torch.Tensor] = {}
+
+    def store(self, x: torch.Tensor) -> torch.Tensor:
+        return x if self.store_dtype is None else x.to(self.store_dtype).to(torch.float32)
+
+    def weight(self, w: W, name: str) -> torch.Tensor:
+        """dequantised e4m3 copy of w[name] (q/k/v rows are quantised row by row, so the engine's fused qkv matrix gives the same)"""
+        t = self._dq.get(name)
+        if t is None:
+            t = self._dq[name] = qdq_e4m3_rows(w[name])
+        return t
+
+    def act(self, x: torch.Tensor) -> torch.Tensor:
+        if self.act_dtype is not None:
+            x = x.to(self.act_dtype).to(torch.float32)
+        return qdq_e4m3_rows(x)
+
+    def lin(self, w: W, name: str, x: torch.Tensor, b, phase: str) -> torch.Tensor:
+        """phase 'prefill' = a multi-row product of svln_generate's prefill; 'decode' = the single-row decode step"""
+        if phase == "prefill" and self.gemm:
+            return linear(self.act(x), self.weight(w, name), b)
+        if phase == "decode" and self.decode:
+            return linear(x, self.weight(w, name), b)
+        return linear(x, w[name], b)
 
 
 # ----------------------------------------------------------------------------- vision
@@ -260,19 +323,27 @@ class KVCache:
         return self.k[i], self.v[i]
 
 
-def qwen2_layer(w: W, cfg, i: int, x: torch.Tensor, pos: torch.Tensor, cache: KVCache) -> torch.Tensor:
+def qwen2_layer(w: W, cfg, i: int, x: torch.Tensor, pos: torch.Tensor, cache: KVCache, q8: Optional[Fp8Emu] = None,
+                phase: str = "prefill") -> torch.Tensor:
     """One decoder layer on T new positions (modeling_qwen2.py:195-235,269-299).
-    x [T,H]; pos [T] absolute positions; causal over cache + new (bottom-right aligned)."""
+    x [T,H]; pos [T] absolute positions; causal over cache + new (bottom-right aligned).
+    q8 / phase: opt-in e4m3 emulation of the seven projections (Fp8Emu; extension, no reference counterpart)."""
     L = f"model.layers.{i}."
     T = x.shape[0]
     nq, nkv, hd = cfg.q_heads, cfg.kv_heads, cfg.head_dim
-    h = rms_norm(x, w[L + "input_layernorm.weight"], cfg.rms_eps)
-    q = linear(h, w[L + "self_attn.q_proj.weight"], w[L + "self_attn.q_proj.bias"]).view(T, nq, hd)
-    k = linear(h, w[L + "self_attn.k_proj.weight"], w[L + "self_attn.k_proj.bias"]).view(T, nkv, hd)
-    v = linear(h, w[L + "self_attn.v_proj.weight"], w[L + "self_attn.v_proj.bias"]).view(T, nkv, hd)
+    if q8 is None:
+        lin = lambda name, t, b=None: linear(t, w[L + name + ".weight"], b)
+        st = lambda t: t
+    else:
+        lin = lambda name, t, b=None: q8.lin(w, L + name + ".weight", t, b, phase)
+        st = q8.store                                # identity unless the emulation also restates the engine's storage rounding
+    h = st(rms_norm(x, w[L + "input_layernorm.weight"], cfg.rms_eps))
+    q = st(lin("self_attn.q_proj", h, w[L + "self_attn.q_proj.bias"])).view(T, nq, hd)
+    k = st(lin("self_attn.k_proj", h, w[L + "self_attn.k_proj.bias"])).view(T, nkv, hd)
+    v = st(lin("self_attn.v_proj", h, w[L + "self_attn.v_proj.bias"])).view(T, nkv, hd)
     cos, sin = rope_cos_sin(pos, hd, cfg.rope_theta)
-    q = q * cos[:, None] + rotate_half(q) * sin[:, None]
-    k = k * cos[:, None] + rotate_half(k) * sin[:, None]
+    q = st(q * cos[:, None] + rotate_half(q) * sin[:, None])
+    k = st(k * cos[:, None] + rotate_half(k) * sin[:, None])
     kc, vc = cache.update(i, k.transpose(0, 1), v.transpose(0, 1))     # [nkv, len, hd]
     S = kc.shape[1]
     g = nq // nkv
@@ -284,24 +355,31 @@ def qwen2_layer(w: W, cfg, i: int, x: torch.Tensor, pos: torch.Tensor, cache: KV
     s = s - s.amax(-1, keepdim=True)
     p = torch.exp(s)
     p = p / p.sum(-1, keepdim=True)
-    o = torch.einsum("kgts,ksd->kgtd", p, vc).reshape(nq, T, hd).transpose(0, 1).reshape(T, nq * hd)
-    x = x + linear(o, w[L + "self_attn.o_proj.weight"])
-    h = rms_norm(x, w[L + "post_attention_layernorm.weight"], cfg.rms_eps)
-    gate = linear(h, w[L + "mlp.gate_proj.weight"])
-    up = linear(h, w[L + "mlp.up_proj.weight"])
-    return x + linear(silu(gate) * up, w[L + "mlp.down_proj.weight"])
+    o = st(torch.einsum("kgts,ksd->kgtd", p, vc).reshape(nq, T, hd).transpose(0, 1).reshape(T, nq * hd))
+    x = st(x + lin("self_attn.o_proj", o))
+    h = st(rms_norm(x, w[L + "post_attention_layernorm.weight"], cfg.rms_eps))
+    gate = lin("mlp.gate_proj", h)
+    up = lin("mlp.up_proj", h)
+    return st(x + lin("mlp.down_proj", st(silu(gate) * up)))
 
 
-def qwen2_forward(w: W, cfg, x: torch.Tensor, start: int, cache: KVCache):
-    """Run T new positions [start, start+T) through all layers; returns final-norm hidden [T,H]."""
+def qwen2_forward(w: W, cfg, x: torch.Tensor, start: int, cache: KVCache, q8: Optional[Fp8Emu] = None, phase: str = "prefill",
+                  layer_taps: Optional[list] = None):
+    """Run T new positions [start, start+T) through all layers; returns final-norm hidden [T,H].
+    layer_taps (test tap): receives the LAST row of the residual stream after every layer."""
     assert len(cache) == start
     pos = torch.arange(start, start + x.shape[0])
     for i in range(cfg.layers):
-        x = qwen2_layer(w, cfg, i, x, pos, cache)
+        x = qwen2_layer(w, cfg, i, x, pos, cache, q8, phase)
+        if layer_taps is not None:
+            layer_taps.append(x[-1].clone())
     return rms_norm(x, w["model.norm.weight"], cfg.rms_eps)
 
 
-def lm_logits(w: W, h_last: torch.Tensor) -> torch.Tensor:
+def lm_logits(w: W, h_last: torch.Tensor, q8: Optional[Fp8Emu] = None) -> torch.Tensor:
+    """q8 with .decode: the engine's lm_head GEMV streams the e4m3 copy for the prefill's token too (svln_set_fp8_decode)"""
+    if q8 is not None and q8.decode:
+        return h_last @ q8.weight(w, "lm_head.weight").t()
     return h_last @ w["lm_head.weight"].t()
 
 
@@ -339,9 +417,12 @@ class OracleStreamVLN:
     """Same call surface as the reference's StreamVLNForCausalLM for the streaming path
     (reset / reset_for_env / generate), computing everything in fp32 on the CPU."""
 
-    def __init__(self, cfg, weights: Dict[str, np.ndarray], num_history: Optional[int] = None, memory_keep: int = 0):
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], num_history: Optional[int] = None, memory_keep: int = 0,
+                 fp8: Optional[Fp8Emu] = None):
         from types import SimpleNamespace
         self.cfg = cfg
+        self.fp8 = fp8                          # opt-in e4m3 emulation (extension, no reference counterpart); None = the reference's arithmetic
+        self.layer_taps: List[torch.Tensor] = []   # last-row residual stream after every layer of the latest prefill (test tap)
         # the two call-time knobs of the reference, under the reference's attribute names
         self.config = SimpleNamespace(tokenizer_model_max_length=None)          # stream_video_vln.py:241
         self.generation_config = SimpleNamespace(repetition_penalty=1.0)        # GenerationConfig default
@@ -381,15 +462,16 @@ class OracleStreamVLN:
         P, L_total = len(cache), E.shape[0]
         assert L_total > P
         eos = set(int(e) for e in eos_token_ids)
-        h = qwen2_forward(w, cfg, E[P:], P, cache)[-1]
+        self.layer_taps = []
+        h = qwen2_forward(w, cfg, E[P:], P, cache, self.fp8, "prefill", self.layer_taps)[-1]
         out, hid, margins = [], [], []
         pen = float(getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0)
         while True:
-            tok, margin = greedy_pick(repetition_penalty(lm_logits(w, h), out, pen))
+            tok, margin = greedy_pick(repetition_penalty(lm_logits(w, h, self.fp8), out, pen))
             out.append(tok); hid.append(h.clone()); margins.append(margin)
             if tok in eos or len(out) >= max_new_tokens:
                 break
             x = w["model.embed_tokens.weight"][tok][None]
-            h = qwen2_forward(w, cfg, x, len(cache), cache)[-1]
+            h = qwen2_forward(w, cfg, x, len(cache), cache, self.fp8, "decode")[-1]
         assert len(cache) == L_total + len(out) - 1
         return GenerateOutput(torch.tensor([out], dtype=torch.long), cache, torch.stack(hid), margins)

@@ -63,6 +63,9 @@ SIGNATURES = {
     "svln_get_embeds": (_I, [_P, _I, _I, _I, _PF]),
     "svln_get_frame_feats": (_I, [_P, _I, _I, _PF]),
     "svln_get_top2": (_I, [_P, _PF]),
+    "svln_set_layer_taps": (_I, [_P, _I, _I]),
+    "svln_get_layer_taps": (_I, [_P, _PF]),
+    "svln_get_layer_probe": (_I, [_P, _I, _PF, _I64, _PI32, _PI32]),
     "svln_set_decode_graph": (_I, [_P, _I]),
     "svln_set_fp8_decode": (_I, [_P, _I]),
     "svln_set_fp8_gemm": (_I, [_P, _I]),

@@ -86,6 +86,9 @@ struct EngineBase {
     virtual void set_repetition_penalty(float penalty) = 0;
     virtual void get_hidden_batch(int slot, float* out, int max_rows, int32_t* n_rows) = 0;
     virtual void get_hidden(float* out, int max_rows, int32_t* n_rows) = 0;
+    virtual void set_layer_taps(int enable, int probe_layer) = 0;
+    virtual void get_layer_taps(float* out) = 0;
+    virtual void get_layer_probe(int which, float* out, int64_t max_elems, int32_t* n_rows, int32_t* n_cols) = 0;
     virtual void get_embeds(int env, int start, int n, float* out) = 0;
     virtual void get_feats(int start, int n, float* out) = 0;
     virtual void get_top2(float* out) = 0;
@@ -793,14 +796,18 @@ public:
         for (const Seg& g : segs)
             HIP_CHECK(hipMemcpyAsync(x + (size_t)g.off * H, g.e->embeds + (size_t)g.P * H, (size_t)g.Tn * H * sizeof(T), hipMemcpyDeviceToDevice, st));
         bool xn_ready = false;        // xn already holds rmsnorm(x) * in_norm (written by the previous layer's down_proj epilogue)
+        const bool taps = layer_taps_on && segs.size() == 1 && n_dec == 0;
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
+            const bool probing = taps && i == probe_layer;
+            if (probing) { probe_copy(0, x, M); probe_rows = M; }
             if (!xn_ready) launch_rmsnorm<T>(st, x, L.in_norm, xn, M, H, c.rms_eps);
             // one env's turn alone in the batch: the QKV product's split-K reduce also applies RoPE and appends k / v to its pages
             RopeKvArgs r0; r0.qkv = qkv; r0.ld = qkv_dim; r0.Kpool = L.kpool; r0.Vpool = L.vpool; r0.rope_tab = rope_tab;
             r0.nq = nq; r0.nkv = nkv; r0.dyn_pos = nullptr;
             GemmArgs aq = gemm_args(xn, H, L.qkv_w, H, qkv, qkv_dim, L.qkv_b, nullptr, 0, 0, M, qkv_dim, H, EPI_NONE);
             if (segs.size() == 1 && n_dec == 0) { r0.page_table = segs[0].e->d_pages; r0.T = segs[0].Tn; r0.P = segs[0].P; aq.rope = &r0; }
+            if (probing) probe_copy(6, xn, M);
             const bool roped = llm_gemm(aq, L.qkv8);
             if (n_dec > 0) {
                 AttnArgs a = batched_decode_attn_args(L, n_dec);
@@ -819,14 +826,21 @@ public:
             // the split-K reduce of o_proj / down_proj also emits the following RMSNorm when it can (T <= 256 rows)
             GemmArgs ao = gemm_args(attn, qd, L.o_w, qd, x, H, nullptr, x, H, 0, M, H, qd, EPI_NONE);
             ao.norm_w = L.post_norm; ao.norm_out = xn; ao.norm_eps = c.rms_eps;
+            if (probing) { probe_copy(2, attn, M); probe_copy(7, qkv, M); }
             if (!llm_gemm(ao, L.o8)) launch_rmsnorm<T>(st, x, L.post_norm, xn, M, H, c.rms_eps);
+            if (probing) { probe_copy(3, x, M); probe_copy(4, xn, M); }
             const bool pp = i == 0 && probe_on && M <= 256 && n_dec == 0 && pprobe_used + 2 <= pprobe_ev.size();
             if (pp) HIP_CHECK(hipEventRecord(pprobe_ev[pprobe_used], st));
             llm_gemm(gemm_args(xn, H, L.gu_w, H, hbuf, I, nullptr, nullptr, 0, 0, M, 2 * I, H, EPI_SWIGLU), L.gu8);
             if (pp) { HIP_CHECK(hipEventRecord(pprobe_ev[pprobe_used + 1], st)); pprobe_used += 2; pprobe_rows += M; }
+            if (probing) probe_copy(5, hbuf, M);
             GemmArgs ad = gemm_args(hbuf, I, L.down_w, I, x, H, nullptr, x, H, 0, M, H, I, EPI_NONE);
             if (i + 1 < c.layers) { ad.norm_w = ll[i + 1].in_norm; ad.norm_out = xn; ad.norm_eps = c.rms_eps; }
             xn_ready = llm_gemm(ad, L.down8);
+            if (taps) {
+                HIP_CHECK(hipMemcpyAsync(layer_tap + (size_t)i * H, x + (size_t)(M - 1) * H, (size_t)H * sizeof(T), hipMemcpyDeviceToDevice, st));
+                if (probing) probe_copy(1, x, M);
+            }
         }
     }
     AttnArgs batched_decode_attn_args(const LLayer& L, int B) {
@@ -901,14 +915,31 @@ public:
     }
     // graph of: ops [lo, hi) of one decode step (+ the head when hi is the end of the step), then `more` further whole steps
     hipGraphExec_t capture(Env& e, int lo, int hi, int more = 0) {
-        hipGraph_t g; hipGraphExec_t ex;
+        return capture_graph([&] {
+            decode_ops(e, lo, hi);
+            if (hi == total_ops()) head(x, 0, true);       // (the tap row comes from the device)
+            for (int k = 0; k < more; ++k) { decode_ops(e, 0, total_ops()); head(x, 0, true); }
+        });
+    }
+    // Capture `body` (launches on `st` only) into an executable graph.  An exception thrown inside the capture (REQUIRE / HIP_CHECK /
+    // LAUNCH_CHECK of a launcher) must not leave the stream in capture mode: the capture is ended, the partial graph destroyed and the
+    // host-side state a captured product may have left behind (act8_src) reset before the exception travels on.
+    template <typename F> hipGraphExec_t capture_graph(F&& body) {
+        hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr;
         HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        decode_ops(e, lo, hi);
-        if (hi == total_ops()) head(x, 0, true);       // (the tap row comes from the device)
-        for (int k = 0; k < more; ++k) { decode_ops(e, 0, total_ops()); head(x, 0, true); }
+        try {
+            body();
+        } catch (...) {
+            (void)hipStreamEndCapture(st, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            act8_src = nullptr;
+            throw;
+        }
         HIP_CHECK(hipStreamEndCapture(st, &g));
-        HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
-        HIP_CHECK(hipGraphDestroy(g));
+        const hipError_t inst = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        HIP_CHECK(inst);
         return ex;
     }
     void drop_graphs() {
@@ -931,9 +962,9 @@ public:
         if (use_graph) {
             GraphSet& gs = graphs[env];
             auto get = [&](int key, int lo, int hi, int more) {
-                hipGraphExec_t& ex = gs.ex[key];
-                if (!ex) ex = capture(e, lo, hi, more);
-                return ex;
+                auto it = gs.ex.find(key);
+                if (it == gs.ex.end()) it = gs.ex.emplace(key, capture(e, lo, hi, more)).first;
+                return it->second;
             };
             if (!probing) {
                 HIP_CHECK(hipGraphLaunch(get(steps, 0, n_ops, steps - 1), st));
@@ -1078,7 +1109,16 @@ public:
         for (int k = 0; k < MAXB; ++k) REQUIRE(!jobs[k].used, "repetition_penalty cannot change while turns are in flight");
         HIP_CHECK(hipStreamSynchronize(st));
         if (penalty != 1.0f) ensure_pen_buffers();
-        if (penalty != rep_penalty) drop_graphs();           // the captured lm_head launch holds the flag pointer and the factor
+        if (penalty != rep_penalty) {
+            drop_graphs();           // the captured lm_head launch holds the flag pointer and the factor
+            // flags of the last penalised turn must not survive a change of the factor: an unpenalised generate() in between rewrites
+            // d_out_ids / GenCtl.count without touching them, so the next penalised turn would clear the wrong ids (P -> 1 -> P)
+            if (pen_flags) {
+                HIP_CHECK(hipMemsetAsync(pen_flags, 0, (size_t)V, st));
+                HIP_CHECK(hipMemsetAsync(pen_flags_b, 0, (size_t)MAXB * V, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+        }
         rep_penalty = penalty;
     }
     void set_turn_row_limit(int rows) override { REQUIRE(rows >= 0, "row limit must be >= 0 (0 = none)"); turn_row_limit = rows; }
@@ -1170,16 +1210,10 @@ public:
                 // (B, fp8, penalty) combination is captured once: every run-time value (page tables, positions, fed tokens) is in d_slots / d_tok_b.
                 if (use_graph) {
                     const int key = B | (pen ? 256 : 0) | (fp8_gemm_on ? 512 : 0);
-                    hipGraphExec_t& ex = bgraphs[key];
-                    if (!ex) {
-                        hipGraph_t g;
-                        HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                        decode_ops_batched(B, pen);
-                        HIP_CHECK(hipStreamEndCapture(st, &g));
-                        HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
-                        HIP_CHECK(hipGraphDestroy(g));
-                    }
-                    HIP_CHECK(hipGraphLaunch(ex, st));
+                    auto it = bgraphs.find(key);
+                    if (it == bgraphs.end())      // (a failed capture leaves no entry behind)
+                        it = bgraphs.emplace(key, capture_graph([&] { decode_ops_batched(B, pen); })).first;
+                    HIP_CHECK(hipGraphLaunch(it->second, st));
                 } else {
                     decode_ops_batched(B, pen);
                 }
@@ -1368,6 +1402,40 @@ public:
     }
 
     // ------------------------------------------------------------------------------- taps
+    // Parity taps of the single-env prefill (test infrastructure, off by default): the LAST row of the residual stream after every
+    // decoder layer (error-versus-depth curves), and every row entering / leaving ONE probed layer (a fused layer checked against
+    // the oracle at its own scale, on the engine's own inputs: a whole-stack tolerance would hide an O(1)-wrong stage).
+    // probe buffers of the probed layer: 0 = x entering the layer, 1 = x leaving it, 2 = attention output (the A operand of o_proj),
+    // 3 = x after the attention residual, 4 = post_attention_layernorm(x) (A of gate/up), 5 = silu(gate) * up (A of down_proj)
+    // 6 = input_layernorm(x) (A of the q/k/v product), 7 = the q | k | v buffer after bias and RoPE (v columns: the plain product)
+    static constexpr int N_PROBE = 8;
+    bool layer_taps_on = false; int probe_layer = -1; int probe_rows = 0;
+    T* layer_tap = nullptr; T* probe_buf[N_PROBE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int probe_cols(int which) const { return which == 2 ? nq * 128 : which == 5 ? I : which == 7 ? qkv_dim : H; }
+    void set_layer_taps(int enable, int layer) override {
+        REQUIRE(layer < c.layers, "probe layer out of range");
+        HIP_CHECK(hipStreamSynchronize(st));
+        layer_taps_on = enable != 0;
+        probe_layer = layer_taps_on ? layer : -1;
+        probe_rows = 0;
+        if (layer_taps_on && !layer_tap) layer_tap = dalloc<T>((size_t)c.layers * H, true);
+        if (probe_layer >= 0 && !probe_buf[0])
+            for (int k = 0; k < N_PROBE; ++k) probe_buf[k] = dalloc<T>((size_t)c.max_positions * probe_cols(k));
+    }
+    void probe_copy(int which, const T* src, int M) {
+        HIP_CHECK(hipMemcpyAsync(probe_buf[which], src, (size_t)M * probe_cols(which) * sizeof(T), hipMemcpyDeviceToDevice, st));
+    }
+    void get_layer_taps(float* out) override {
+        REQUIRE(layer_tap != nullptr, "layer taps were never enabled");
+        read_rows_f32(layer_tap, (size_t)c.layers * H, out);
+    }
+    void get_layer_probe(int which, float* out, int64_t max_elems, int32_t* n_rows, int32_t* n_cols) override {
+        REQUIRE(probe_buf[0] != nullptr && which >= 0 && which < N_PROBE, "no such layer probe");
+        const int cols = probe_cols(which);
+        REQUIRE((int64_t)probe_rows * cols <= max_elems, "layer probe: output buffer too small");
+        if (probe_rows > 0) read_rows_f32(probe_buf[which], (size_t)probe_rows * cols, out);
+        *n_rows = probe_rows; *n_cols = cols;
+    }
     void read_rows_f32(const T* src, size_t n, float* out) {
         float* tmp = nullptr;
         HIP_CHECK(hipMalloc((void**)&tmp, n * sizeof(float)));
@@ -1694,6 +1762,11 @@ int svln_generate_fixed(svln_engine* h, int env, int n_tokens, int64_t* out) {
     API_BEGIN_H int32_t n = 0; h->impl->generate(env, n_tokens, nullptr, 0, out, n_tokens, &n, true); API_END
 }
 int svln_get_hidden(svln_engine* h, float* out, int max_rows, int32_t* n_rows) { API_BEGIN_H h->impl->get_hidden(out, max_rows, n_rows); API_END }
+int svln_set_layer_taps(svln_engine* h, int enable, int probe_layer) { API_BEGIN_H h->impl->set_layer_taps(enable, probe_layer); API_END }
+int svln_get_layer_taps(svln_engine* h, float* out) { API_BEGIN_H REQUIRE(out, "null output pointer"); h->impl->get_layer_taps(out); API_END }
+int svln_get_layer_probe(svln_engine* h, int which, float* out, int64_t max_elems, int32_t* n_rows, int32_t* n_cols) {
+    API_BEGIN_H REQUIRE(out && n_rows && n_cols, "null output pointer"); h->impl->get_layer_probe(which, out, max_elems, n_rows, n_cols); API_END
+}
 int svln_get_embeds(svln_engine* h, int env, int start, int n, float* out) { API_BEGIN_H h->impl->get_embeds(env, start, n, out); API_END }
 int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEGIN_H h->impl->get_feats(start, n, out); API_END }
 int svln_get_top2(svln_engine* h, float* out) { API_BEGIN_H h->impl->get_top2(out); API_END }

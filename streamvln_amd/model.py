@@ -272,16 +272,22 @@ class StreamVLNForCausalLM:
 
     def _sync_call_config(self):
         """config.tokenizer_model_max_length and generation_config.repetition_penalty are plain attributes the caller may change
-        between calls (the reference reads them at call time): push them to the engine when they differ from what it holds."""
+        between calls (the reference reads them at call time): push them to the engine when they differ from what it holds.
+        The row limit has no in-flight restriction and is pushed at every call; the penalty cannot change while scheduler turns are
+        in flight (the engine refuses it), so a changed value raises here instead of being ignored."""
         tml = getattr(self.config, "tokenizer_model_max_length", None)
+        if tml is not None and int(tml) < 1:
+            # the reference would splice `new_input_embeds[:0]` -- an empty turn -- and fail further down (stream_video_vln.py:241-244);
+            # the engine's 0 means "no truncation", so 0 must never reach it
+            raise ValueError(f"config.tokenizer_model_max_length must be None (no truncation) or >= 1, got {tml!r}")
         lim = 0 if tml is None else int(tml)
-        if lim < 0:
-            raise ValueError("tokenizer_model_max_length must be >= 0")
         if lim != self._row_limit:
             _check(self._lib.svln_set_turn_row_limit(self._h, lim))
             self._row_limit = lim
         rp = float(getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0)
         if rp != self._rep_penalty:
+            if self._tickets:
+                raise RuntimeError("generation_config.repetition_penalty changed while turns are in flight: collect or cancel them first")
             _check(self._lib.svln_set_repetition_penalty(self._h, rp))
             self._rep_penalty = rp
 
@@ -541,8 +547,7 @@ class StreamVLNForCausalLM:
             raise RuntimeError(f"env_id {env_id} already has a turn in flight")
         if len(self._tickets) >= 8:
             raise RuntimeError("at most 8 turns in flight: collect finished turns with step_batch first")
-        if not self._tickets:
-            self._sync_call_config()          # (the penalty cannot change while turns are in flight)
+        self._sync_call_config()
         on_dev = int(pix.is_cuda)
         if on_dev:
             self._order_engine_after(pix)
@@ -603,6 +608,24 @@ class StreamVLNForCausalLM:
         n = C.c_int32()
         _check(self._lib.svln_get_hidden(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), 64, C.byref(n)))
         return buf[: n.value].copy()
+
+    def set_layer_taps(self, enable: bool, probe_layer: int = -1):
+        """test taps of the prefill: last residual row after every LLM layer; all rows around `probe_layer` (see include/streamvln_hip.h)"""
+        _check(self._lib.svln_set_layer_taps(self._h, int(enable), int(probe_layer)))
+
+    def layer_taps(self) -> np.ndarray:
+        out = np.empty((self.cfg.layers, self.cfg.hidden), dtype=np.float32)
+        _check(self._lib.svln_get_layer_taps(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def layer_probe(self, which: int, max_rows: int = 512) -> np.ndarray:
+        """operand `which` of the probed layer as the last prefill saw it (0 x_in, 1 x_out, 2 attention out, 3 x after attention,
+        4 post-attention norm, 5 SwiGLU product, 6 input norm, 7 q|k|v after RoPE): fp32 [rows, cols]"""
+        widest = max(self.cfg.inter, self.cfg.q_dim + 2 * self.cfg.kv_dim, self.cfg.hidden)
+        out = np.empty(max_rows * widest, dtype=np.float32)
+        n, cols = C.c_int32(), C.c_int32()
+        _check(self._lib.svln_get_layer_probe(self._h, int(which), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n), C.byref(cols)))
+        return out[: n.value * cols.value].reshape(n.value, cols.value).copy()
 
     def env_state(self, env_id=0):
         ne, kl = C.c_int32(), C.c_int32()

@@ -32,6 +32,10 @@ class SyntheticPromptEncoder:
         self.first_len, self.memory_len, self.later_len = first_len, memory_len, later_len
         self._n = 0
 
+    def reset(self):
+        """start the prompt stream over: two runs that should see the same prompts (an A/B of two engine modes) each begin here"""
+        self._n = 0
+
     def _text(self, n: int) -> List[int]:
         lo = min(1000, self.cfg.vocab // 4)
         hi = min(150000, self.cfg.vocab)

@@ -42,7 +42,7 @@ def eos_ids(sc):
 
 def run_scenario(model, sc, preprocess, on_turn=None, device="cpu", image_dtype=torch.float32, steps=None):
     cfg = sc["cfg"]
-    enc = SyntheticPromptEncoder(cfg, seed=7, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
+    enc = SyntheticPromptEncoder(cfg, seed=sc.get("prompt_seed", 7), first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
     agent = StreamingAgent(model, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"],
                            num_history=sc["num_history"], max_new_tokens=sc["max_new"], eos_token_ids=eos_ids(sc),
                            preprocess=preprocess, device=device, image_dtype=image_dtype)

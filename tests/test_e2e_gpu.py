@@ -876,6 +876,31 @@ def test_repetition_penalty_solo_batch_and_scheduler_agree_with_oracle():
     orc.reset(1)
     plain = orc.generate(inputs=reqs[0]["inputs"].numpy(), images=reqs[0]["images"].cpu().numpy(), env_id=0, time_ids=[[0]], max_new_tokens=6).sequences[0].tolist()
     assert m.generate(max_new_tokens=6, eos_token_ids=[], **reqs[0]).sequences[0].tolist() == plain
+    # ... and ON again (P -> 1 -> P): the unpenalised generate above rewrote the engine's id ring without touching the flags
+    # of the last penalised turn; those flags must not leak into this one.  Solo (graph on / off) and scheduler paths vs the oracle.
+    m.generation_config.repetition_penalty = pen
+    for graph in (True, False):
+        m.set_decode_graph(graph)
+        m.reset(NE)
+        for e in (1, 0):
+            got = m.generate(max_new_tokens=6, eos_token_ids=[], **reqs[e]).sequences[0].tolist()
+            assert got == exp[e], ("solo, penalty off -> on", graph, e, got, exp[e])
+    m.reset(NE)
+    outs = m.generate_batch(reqs, max_new_tokens=6, eos_token_ids=[])
+    for e in range(NE):
+        assert outs[e].sequences[0].tolist() == exp[e], ("batch, penalty off -> on", e)
+    # a penalty change while scheduler turns are in flight is refused, not ignored; the row limit may change at any call
+    m.reset(NE)
+    tk = m.submit(max_new_tokens=6, eos_token_ids=[], **reqs[0])
+    m.generation_config.repetition_penalty = 1.0
+    with pytest.raises(RuntimeError, match="in flight"):
+        m.submit(max_new_tokens=6, eos_token_ids=[], **reqs[1])
+    m.generation_config.repetition_penalty = pen
+    m.config.tokenizer_model_max_length = 0
+    with pytest.raises(ValueError, match="tokenizer_model_max_length"):
+        m.submit(max_new_tokens=6, eos_token_ids=[], **reqs[1])
+    m.config.tokenizer_model_max_length = None
+    m.cancel(tk)
     m.close()
 
 
@@ -1143,61 +1168,4 @@ def test_ragged_scheduler_true_width_vs_oracle():
     m.close()
 
 
-# fp8 (e4m3) opt-ins at true width, 4 + 4 layers, full vocabulary: floors on id agreement with the bf16 engine and bounds on the hidden
-# state error against the reference-generated fp32 fixture (measured values are written next to the bounds; bench.py reports the same
-# quantities at full depth on its own line)
-# relative L2 error of the final-norm hidden rows at 4 + 4 layers: weight-only e4m3 (decode GEMVs + lm_head) / e4m3 x e4m3 products with
-# per-row scales (3 mantissa bits on BOTH operands of every prefill product: measured 0.118) / both
-FP8_HIDDEN_REL = {"fp8 decode weights": 0.10, "fp8 MFMA gemms": 0.16, "both": 0.20}
-# Random-init weights give top-2 logit margins of 0.02-0.3 (fixture), the size of the e4m3 logit error itself, so an unconditional
-# agreement rate says nothing here (the first token of true4 has margin 0.02 and flips under an fp8 lm_head).  Asserted instead: every
-# comparable token whose fixture margin exceeds FP8_MARGIN agrees with the bf16 engine; the rate is reported.
-FP8_MARGIN = 0.2
-
-
-def test_fp8_opt_ins_true_width_vs_bf16_and_fixture():
-    sc, g = SCENARIOS["true4_episode"], load_golden("true4_episode")
-    m = _model(sc, torch.bfloat16)
-    log16, taps16 = _run(m, sc)
-    ids16 = [r["out"].sequences[0].tolist() for r in log16]
-    report, failures = [], []
-    for name, on, off in (("fp8 decode weights", lambda: m.set_fp8_decode(True), lambda: m.set_fp8_decode(False)),
-                          ("fp8 MFMA gemms", lambda: m.set_fp8_gemm(True), lambda: m.set_fp8_gemm(False)),
-                          ("both", lambda: (m.set_fp8_decode(True), m.set_fp8_gemm(True)), lambda: (m.set_fp8_decode(False), m.set_fp8_gemm(False)))):
-        on()
-        m.reset(1)
-        log8, taps8 = _run(m, sc)
-        off()
-        agree = total = checked = 0
-        worst16 = worstfx = 0.0
-        for t, r8 in enumerate(log8):
-            ids8, gold = r8["out"].sequences[0].tolist(), g[f"t{t}_ids"].tolist()
-            n = 0
-            while n < len(ids8) and ids8[n] == ids16[t][n]:
-                n += 1
-            agree += n; total += len(ids16[t])
-            margins = g[f"t{t}_margins"]
-            for j in range(min(n + 1, len(ids8))):                  # rows that saw the same inputs as the bf16 run
-                h8, h16 = taps8[t]["hidden"][j], taps16[t]["hidden"][j]
-                worst16 = max(worst16, float(np.linalg.norm(h8 - h16) / np.linalg.norm(h16)))
-                if ids16[t][:j] == gold[:j]:                         # ... and as the fp32 fixture
-                    gh = g[f"t{t}_hidden"][j]
-                    worstfx = max(worstfx, float(np.linalg.norm(h8 - gh) / np.linalg.norm(gh)))
-                    if ids16[t][j] == gold[j] and margins[j] > FP8_MARGIN:
-                        checked += 1
-                        assert ids8[j] == ids16[t][j], (name, t, j, ids8, ids16[t], margins)
-            if n < len(ids16[t]):
-                break
-        report.append(f"{name}: {agree}/{total} ids agree with bf16 before the first divergence ({checked} tokens with fixture margin > {FP8_MARGIN} "
-                      f"checked: all agree), hidden rel err vs bf16 {worst16:.4f}, vs fp32 fixture {worstfx:.4f}")
-        failures += [(name, worst16, worstfx)] if not (worst16 < FP8_HIDDEN_REL[name] and worstfx < FP8_HIDDEN_REL[name]) else []
-    for line in report:
-        print(line)
-        _note("fp8_true_width", "TRUE4 " + line)
-    assert not failures, failures
-    m.reset(1)
-    log1, taps1 = _run(m, sc)                                       # everything off again: bf16 results restored exactly
-    assert [r["out"].sequences[0].tolist() for r in log1] == ids16
-    for a, b in zip(taps16, taps1):
-        assert np.array_equal(a["hidden"], b["hidden"])
-    m.close()
+# (the fp8 opt-ins at true width and at full depth are checked against the quantisation-emulating oracle in tests/test_fp8_gpu.py)

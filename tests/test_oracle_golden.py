@@ -108,3 +108,51 @@ def test_memory_prune_extension_definition():
     k = [i for i in range(50) if float(score[i]) <= float(score[10])]
     idx2, _ = O.prune_memory_tokens(mem, len(k) - 1)     # cut between the tied pair: 10 stays, 20 goes
     assert 10 in idx2.tolist() and 20 not in idx2.tolist()
+
+
+def test_fp8_emulation_arithmetic_and_neutral_mode():
+    """oracle.Fp8Emu (extension, no reference counterpart): the per-row e4m3 quantise -> dequantise restates gemv.hip quant_fp8_rows_kernel
+    (scale = amax / 448, 1 for a zero row, RNE, idempotent on its own output, every value a multiple of an e4m3 step of its row);
+    with both modes off the oracle's arithmetic -- hence the reference-pinned fixture -- is untouched; with them on it changes."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 64, generator=g) * torch.tensor([1e-3, 1.0, 50.0, 3e4, 1.0, 1.0])[:, None]
+    x[4] = 0.0
+    x[5, 0] = 1000.0                                      # an outlier sets the row's scale
+    y = O.qdq_e4m3_rows(x)
+    assert torch.equal(O.qdq_e4m3_rows(y), y)             # idempotent
+    assert torch.equal(y[4], torch.zeros(64)) and float(y[5, 0]) == 1000.0
+    sc = x.abs().amax(-1, keepdim=True) / 448.0
+    sc[4] = 1.0
+    q = y / sc
+    assert torch.allclose(q, q.to(torch.float8_e4m3fn).float(), rtol=1e-6, atol=0)   # every dequantised value sits on the e4m3 grid of its row
+    rel = ((y - x).norm(dim=1) / x.norm(dim=1).clamp(min=1e-30))[:4]
+    assert float(rel.max()) < 0.04 and float(rel.min()) > 0.01         # 3 mantissa bits: ~2.5 % per element
+    assert float((y - x).abs().max() / x.abs().max()) <= 2.0 ** -4
+    # the emulation object: weight cache, activation rounding to bf16 first
+    emu = O.Fp8Emu(decode=True, gemm=True)
+    w = {"a.weight": torch.randn(8, 32, generator=g)}
+    assert emu.weight(w, "a.weight") is emu.weight(w, "a.weight")
+    a = torch.randn(3, 32, generator=g)
+    assert torch.equal(emu.act(a), O.qdq_e4m3_rows(a.bfloat16().float()))
+    assert torch.equal(emu.lin(w, "a.weight", a, None, "decode"), a @ emu.weight(w, "a.weight").t())
+    assert torch.equal(emu.lin(w, "a.weight", a, None, "prefill"), emu.act(a) @ emu.weight(w, "a.weight").t())
+    off = O.Fp8Emu()
+    assert torch.equal(off.lin(w, "a.weight", a, None, "prefill"), a @ w["a.weight"].t())
+    # end to end on the tiny episode's first turns: neutral emulation == plain oracle bit for bit; the modes change the hidden rows
+    sc_t = dict(SCENARIOS["tiny_episode"], eos_mod=0)
+    cfg = sc_t["cfg"]
+    sd = W.synth_state_dict(cfg, SEED)
+    pre = lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb))
+    runs = {}
+    for key, fp8 in (("plain", None), ("neutral", O.Fp8Emu()), ("decode", O.Fp8Emu(decode=True)), ("gemm", O.Fp8Emu(gemm=True))):
+        orc = O.OracleStreamVLN(cfg, sd, num_history=sc_t["num_history"], fp8=fp8)
+        log = run_scenario(orc, sc_t, preprocess=pre, steps=5)
+        runs[key] = [(r["out"].sequences[0].tolist(), r["out"].hidden.numpy()) for r in log]
+        assert len(orc.layer_taps) == cfg.layers
+    assert runs["plain"][0][0] == runs["neutral"][0][0] and np.array_equal(runs["plain"][0][1], runs["neutral"][0][1])
+    h0 = runs["plain"][0][1]
+    assert np.array_equal(runs["decode"][0][1][0], h0[0])              # weight-only decode mode: the prefill row is untouched ...
+    d = np.linalg.norm(runs["decode"][0][1][1] - h0[1]) / np.linalg.norm(h0[1])
+    assert (0.0 < d < 0.3) or runs["decode"][0][0][0] != runs["plain"][0][0][0]     # ... the decode rows move (unless the e4m3 lm_head already changed the fed token)
+    gmm = np.linalg.norm(runs["gemm"][0][1][0] - h0[0]) / np.linalg.norm(h0[0])
+    assert 0.005 < gmm < 0.3, gmm
