@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--pageable-frames", action="store_true", help="camera frames in ordinary numpy arrays instead of the engine's pinned frame ring")
+    ap.add_argument("--own-torch-stream", action="store_true", help="leave torch on its default stream (cross-stream ordering per frame / turn) instead of the engine's")
     return ap.parse_args()
 
 
@@ -95,12 +97,21 @@ class Runner:
     every env step preprocesses its frame (streamvln_eval.py:271-274 -> here upload + HIP bicubic kernel), every 4th step runs a
     model turn."""
 
-    def __init__(self, model, cfg, rank):
+    def __init__(self, model, cfg, rank, frame_ring=True):
         from streamvln_amd.agent import StreamingAgent
         from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
         self.proc = model.get_vision_tower().image_processor
         assert self.proc.backend == "hip"
-        self.raw = [synthetic_frame(rank, s) for s in range(EP_STEPS)]          # uint8 [480,640,3], host
+        # the camera side of the loop: uint8 [480,640,3] frames in host memory.  With the engine's pinned frame ring (default) the
+        # "camera" writes each frame into a ring slot, which the image processor then reads in place; --pageable-frames keeps them in
+        # ordinary numpy arrays (one 921 KB staging copy per frame inside the processor, as in rounds 1-3).
+        if frame_ring:
+            ring = model.frame_ring(EP_STEPS, 480, 640)
+            for s in range(EP_STEPS):
+                ring[s][...] = synthetic_frame(rank, s)
+            self.raw = [ring[s] for s in range(EP_STEPS)]
+        else:
+            self.raw = [synthetic_frame(rank, s) for s in range(EP_STEPS)]
         self.pre_s = 0.0                                                        # wall seconds inside the image processor
         self.agent = StreamingAgent(model, SyntheticPromptEncoder(cfg), num_frames=NUM_FRAMES, num_future_steps=NUM_FUTURE,
                                     num_history=NUM_HISTORY, device="cuda", max_new_tokens=DECODE_TOKENS, eos_token_ids=(),
@@ -284,7 +295,9 @@ def main():
     model.load_synthetic(a.seed)
     model.model.num_history = NUM_HISTORY
     model.set_decode_graph(not a.no_graph)
-    run = Runner(model, cfg, rank)
+    run = Runner(model, cfg, rank, frame_ring=not a.pageable_frames)
+    if not a.own_torch_stream:
+        torch.cuda.set_stream(model.torch_stream)       # the harness's own tensor ops (stack / to) run on the engine's stream: no cross-stream ordering
     lib, h = model._lib, model._h
     import ctypes as C
 
@@ -470,7 +483,8 @@ def main():
                                    "8-frame window (num_frames 32 / future 4 / history 8), 5 decode tokens/turn, 1 env per GPU; "
                                    "step = one model turn = 4 env steps, each preprocessing its frame (upload + HIP bicubic) inside "
                                    "the timed region", "model_config": a.config, "envs_per_gpu": 1,
-                       "decode_graph": not a.no_graph, "parallelism": f"episode-parallel x{world}",
+                       "decode_graph": not a.no_graph, "frames": "pageable host arrays" if a.pageable_frames else "engine's pinned frame ring (host)",
+                       "parallelism": f"episode-parallel x{world}",
                        "dist_backend": dist.get_backend() if dist.is_initialized() else None},
             "per_gpu": round(value / world, 2),
             "p50_ms_per_turn": round(float(np.median(lat)) * 1e3, 3),

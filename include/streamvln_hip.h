@@ -72,6 +72,14 @@ int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int
  * or the engine's stream must have been ordered behind it -- before this call. */
 int svln_preprocess_frames_enqueue(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev);
 int svln_engine_stream(svln_engine* h, void** stream);
+/* Engine-owned frame ring: `slots` frames of height x width x 3 bytes in pinned, device-mapped host memory (*host_base, slots
+ * *slot_stride bytes apart, 256-byte aligned).  The camera / simulator side writes its RGB frames into the slots; a frame passed to
+ * svln_preprocess_frames[_enqueue] (on_device = 0) whose bytes lie inside the ring is read by the GPU where it is -- the staging copy on
+ * the host (921 KB per 640x480 frame) disappears.  Any other host pointer takes the staging path as before.  A slot may be rewritten
+ * once the upload that last read it has run: svln_frame_ring_wait(slot) returns when that is the case (immediately if none is pending).
+ * A second call replaces the ring (the old memory is freed). */
+int svln_frame_ring(svln_engine* h, int slots, int height, int width, uint8_t** host_base, int64_t* slot_stride);
+int svln_frame_ring_wait(svln_engine* h, int slot);
 int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset);
 
 /* -- splice: prepare_inputs_labels_for_multimodal (stream_video_vln.py:182-238) for one env.
@@ -90,6 +98,19 @@ int svln_set_turn_row_limit(svln_engine* h, int rows);
  * max_new_tokens; afterwards kv_len = n_embeds + n_out - 1. */
 int svln_generate(svln_engine* h, int env, int max_new_tokens, const int64_t* eos_ids, int n_eos, int64_t* out_ids,
                   int out_cap, int32_t* n_out);
+/* -- ONE call per model turn: what StreamVLNForCausalLM.generate does between the harness's call and its return
+ * (stream_video_vln.py:353-407) = svln_encode_frames(pixels) ; new_window (the caller passed past_key_values=None): svln_kv_reset ;
+ * new_episode (curr_t == 0) and the env holds rows: svln_reset_env ; svln_append_turn(ids, n_memory) ; svln_generate.  *kv_len (optional)
+ * = the env's cache length afterwards (the KV handle the Python class hands back).  Same results and errors as the five calls. */
+typedef struct svln_turn_args {
+    const float* pixels; int32_t n_frames; int32_t pixels_on_device;     /* fp32 [n_frames,3,S,S] */
+    int32_t env;
+    const int64_t* ids; int32_t n_ids; int32_t n_memory;                /* text ids + sentinels; first n_memory frames = <memory> block */
+    int32_t new_window, new_episode;
+    int32_t max_new_tokens;
+    const int64_t* eos_ids; int32_t n_eos;
+} svln_turn_args;
+int svln_turn(svln_engine* h, const svln_turn_args* a, int64_t* out_ids, int out_cap, int32_t* n_out, int32_t* kv_len);
 /* generation_config.repetition_penalty of a checkpoint: transformers' RepetitionPenaltyLogitsProcessor -- applied by
  * GenerationMixin under greedy decoding too -- on the fp32 logits of every step, over the ids generated so far in the turn (the prompt is
  * passed as inputs_embeds, so it has no ids): logit < 0 ? logit * penalty : logit / penalty.  1 = off (default).  Applies to svln_generate,

@@ -26,6 +26,18 @@ class SvlnConfig(C.Structure):
     ]
 
 
+class SvlnTurnArgs(C.Structure):
+    """svln_turn_args of include/streamvln_hip.h"""
+    _fields_ = [
+        ("pixels", C.c_void_p), ("n_frames", C.c_int32), ("pixels_on_device", C.c_int32),
+        ("env", C.c_int32),
+        ("ids", C.c_void_p), ("n_ids", C.c_int32), ("n_memory", C.c_int32),
+        ("new_window", C.c_int32), ("new_episode", C.c_int32),
+        ("max_new_tokens", C.c_int32),
+        ("eos_ids", C.c_void_p), ("n_eos", C.c_int32),
+    ]
+
+
 _P, _I, _F, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _PI32, _PI64, _PF, _PD = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_double)
 
@@ -47,6 +59,9 @@ SIGNATURES = {
     "svln_preprocess_frames_enqueue": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "svln_engine_stream": (_I, [_P, C.POINTER(C.c_void_p)]),
     "svln_preprocess_time": (_I, [_P, _PD, _PI64, _I]),
+    "svln_frame_ring": (_I, [_P, _I, _I, _I, C.POINTER(C.c_void_p), _PI64]),
+    "svln_frame_ring_wait": (_I, [_P, _I]),
+    "svln_turn": (_I, [_P, C.POINTER(SvlnTurnArgs), _PI64, _I, _PI32, _PI32]),
     "svln_append_turn": (_I, [_P, _I, _PI64, _I, _I]),
     "svln_append_turn_at": (_I, [_P, _I, _PI64, _I, _I, _I]),
     "svln_generate_batch": (_I, [_P, _PI32, _I, _I, _PI64, _I, _PI64, _I, _PI32]),

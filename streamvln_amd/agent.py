@@ -67,6 +67,7 @@ class StreamingAgent:
             preprocess = lambda rgb: proc.preprocess_array(rgb)
         self.preprocess = preprocess
         self.turn_log: List[dict] = []
+        self._aux: dict = {}
         self.pending_turn = False          # AsyncBatchedAgents: the model turn of the current env step has returned, the step itself is pending
         self.reset_memory()
 
@@ -98,10 +99,14 @@ class StreamingAgent:
             images = self.rgb_list[hist] + images
         V = len(images)
         self._pending = {"step_id": self.step_id, "n_inputs": int(ids.shape[1]), "views": V, "memory": bool(with_memory)}
+        # torch.stack(images) of the reference (streamvln_eval.py:313-321); one view: the same values as a view of the frame (no copy kernel)
+        stacked = images[0].unsqueeze(0) if V == 1 else self._stack_views(images)
+        aux = self._aux.get(V)
+        if aux is None:              # depths / poses / intrinsics are built by the reference callers and ignored by the model
+            aux = self._aux[V] = (torch.zeros(1, V, 1, 1), torch.zeros(1, V, 4, 4), torch.zeros(1, V, 4, 4))
         return {
-            "images": self._stack_views(images).unsqueeze(0).to(self.device).to(self.image_dtype),
-            # depths / poses / intrinsics are built by the reference callers and ignored by the model
-            "depths": torch.zeros(1, V, 1, 1), "poses": torch.zeros(1, V, 4, 4), "intrinsics": torch.zeros(1, V, 4, 4),
+            "images": stacked.unsqueeze(0).to(self.device).to(self.image_dtype),
+            "depths": aux[0], "poses": aux[1], "intrinsics": aux[2],
             "inputs": ids.to(self.ids_device), "env_id": env_id, "time_ids": [list(self.time_ids)], "task_type": [0],
             "do_sample": False, "num_beams": 1, "max_new_tokens": self.max_new_tokens, "use_cache": True,
             "return_dict_in_generate": True, "past_key_values": self.past_key_values, "eos_token_ids": self.eos_token_ids,

@@ -73,6 +73,9 @@ struct EngineBase {
     virtual void encode_frames(const float* pixels, int F, int on_device) = 0;
     virtual void preprocess_frames(const uint8_t* rgb, int n, int height, int width, int on_device, float* out_dev, bool wait) = 0;
     virtual void* stream_handle() = 0;
+    virtual void frame_ring(int slots, int height, int width, uint8_t** base, int64_t* stride) = 0;
+    virtual void frame_ring_wait(int slot) = 0;
+    virtual void turn(const svln_turn_args& a, int64_t* out, int cap, int32_t* n_out, int32_t* kv_len) = 0;
     virtual void preprocess_time(double* ms, int64_t* frames, int reset) = 0;
     virtual int device_id() const = 0;
     virtual void append_turn(int env, const int64_t* ids, int n, int frame_base, int n_memory) = 0;
@@ -377,6 +380,8 @@ public:
         }
         for (auto& pr : pp_ring) { if (pr.a) (void)hipEventDestroy(pr.a); if (pr.b) (void)hipEventDestroy(pr.b); }
         if (src_ev) (void)hipEventDestroy(src_ev);
+        for (auto ev : ring_ev) (void)hipEventDestroy(ev);
+        if (ring_host) (void)hipHostFree(ring_host);
         for (auto e : probe_ev) (void)hipEventDestroy(e);
         for (auto e : pprobe_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
@@ -659,6 +664,56 @@ public:
         rs_tabs.push_back(t);
         return rs_tabs.back().dev;
     }
+    // Engine-owned pinned frame ring (svln_frame_ring): `slots` frames of height x width x 3 bytes in pinned, device-mapped host memory.
+    // A frame handed to svln_preprocess_frames* that lies INSIDE the ring is read by the upload kernel where it is -- no staging copy on
+    // the host (921 KB per 640x480 frame).  The camera / simulator side writes frames into the slots; a slot may be rewritten once the
+    // upload that last read it has run (svln_frame_ring_wait).
+    uint8_t *ring_host = nullptr, *ring_dev = nullptr; size_t ring_stride = 0, ring_frame_bytes = 0; int ring_slots = 0;
+    std::vector<hipEvent_t> ring_ev; std::vector<char> ring_pending;
+    void frame_ring(int slots, int height, int width, uint8_t** base, int64_t* stride) override {
+        REQUIRE(slots >= 1 && height >= 1 && width >= 1, "frame ring: bad geometry");
+        REQUIRE(base && stride, "null output pointer");
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (auto ev : ring_ev) (void)hipEventDestroy(ev);
+        ring_ev.clear(); ring_pending.clear();
+        if (ring_host) { (void)hipHostFree(ring_host); ring_host = nullptr; ring_dev = nullptr; }
+        ring_frame_bytes = (size_t)height * width * 3;
+        ring_stride = (ring_frame_bytes + 255) / 256 * 256;            // slots start 256-byte aligned (the upload kernel moves 16-byte granules)
+        ring_slots = slots;
+        HIP_CHECK(hipHostMalloc((void**)&ring_host, ring_stride * slots + 256));
+        HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring_host, 0));
+        ring_ev.resize(slots); ring_pending.assign(slots, 0);
+        for (auto& ev : ring_ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        *base = ring_host; *stride = (int64_t)ring_stride;
+    }
+    void frame_ring_wait(int slot) override {
+        REQUIRE(slot >= 0 && slot < ring_slots, "frame ring: no such slot");
+        if (ring_pending[slot]) { HIP_CHECK(hipEventSynchronize(ring_ev[slot])); ring_pending[slot] = 0; }
+    }
+    // device-visible address of a host frame batch that lies inside the ring (16-byte aligned, contiguous), else null
+    const uint8_t* ring_lookup(const uint8_t* rgb, size_t bytes, int n) const {
+        if (!ring_host || rgb < ring_host || rgb + bytes > ring_host + ring_stride * ring_slots) return nullptr;
+        const size_t off = (size_t)(rgb - ring_host);
+        if (off % 16 != 0) return nullptr;
+        if (n > 1 && ring_stride != ring_frame_bytes) return nullptr;      // padded slots: a multi-frame batch is not contiguous
+        return ring_dev + off;
+    }
+    void ring_mark(const uint8_t* rgb, size_t bytes) {                      // the slots this upload reads: busy until the event fires
+        const int s0 = (int)((size_t)(rgb - ring_host) / ring_stride), s1 = (int)((size_t)(rgb - ring_host + bytes - 1) / ring_stride);
+        for (int k = s0; k <= s1 && k < ring_slots; ++k) { HIP_CHECK(hipEventRecord(ring_ev[k], st)); ring_pending[k] = 1; }
+    }
+    // One model turn behind ONE call (SURVEY.md 8b `svln_turn`): encode_rgbd + the KV / embeds bookkeeping of StreamVLNForCausalLM.generate +
+    // splice + greedy generation -- svln_encode_frames, svln_kv_reset / svln_reset_env, svln_append_turn, svln_generate in that order.
+    void turn(const svln_turn_args& a, int64_t* out, int cap, int32_t* n_out, int32_t* kv_len) override {
+        Env& e = env_at(a.env);
+        REQUIRE(a.ids && a.n_ids >= 1 && out && n_out, "svln_turn: null / empty argument");
+        encode_frames(a.pixels, a.n_frames, a.pixels_on_device);
+        if (a.new_window) kv_reset(a.env);                      // past_key_values = None (streamvln_eval.py:349)
+        if (a.new_episode && e.n_embeds != 0) reset_env(a.env); // curr_t == 0: the env's inputs_embeds start over (stream_video_vln.py:396-401)
+        append_turn(a.env, a.ids, a.n_ids, 0, a.n_memory);
+        generate(a.env, a.max_new_tokens, a.eos_ids, a.n_eos, out, cap, n_out, false);
+        if (kv_len) *kv_len = e.kv_len;
+    }
     void preprocess_frames(const uint8_t* rgb, int n, int Hh, int Ww, int on_device, float* out_dev, bool wait) override {
         REQUIRE(rgb && out_dev, "null frame / output pointer");
         REQUIRE(n >= 1 && Hh >= 1 && Ww >= 1, "bad frame geometry");
@@ -687,6 +742,9 @@ public:
         HIP_CHECK(hipEventRecord(pr.a, st));
         if (on_device) {
             HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, bytes, hipMemcpyDeviceToDevice, st));
+        } else if (const uint8_t* rd = ring_lookup(rgb, bytes, n)) {
+            launch_upload(st, rd, d_rgb, bytes);             // the frame sits in the engine's pinned ring: read it where it is
+            ring_mark(rgb, bytes);
         } else {
             const int b = h_cur; h_cur ^= 1;
             if (h_rgb_cap[b] < bytes) {
@@ -1725,6 +1783,13 @@ int svln_preprocess_frames(svln_engine* h, const uint8_t* rgb, int n_frames, int
 }
 int svln_preprocess_frames_enqueue(svln_engine* h, const uint8_t* rgb, int n_frames, int height, int width, int on_device, float* out_dev) {
     API_BEGIN_H h->impl->preprocess_frames(rgb, n_frames, height, width, on_device, out_dev, false); API_END
+}
+int svln_frame_ring(svln_engine* h, int slots, int height, int width, uint8_t** host_base, int64_t* slot_stride) {
+    API_BEGIN_H h->impl->frame_ring(slots, height, width, host_base, slot_stride); API_END
+}
+int svln_frame_ring_wait(svln_engine* h, int slot) { API_BEGIN_H h->impl->frame_ring_wait(slot); API_END }
+int svln_turn(svln_engine* h, const svln_turn_args* a, int64_t* out_ids, int out_cap, int32_t* n_out, int32_t* kv_len) {
+    API_BEGIN_H REQUIRE(a, "null argument"); h->impl->turn(*a, out_ids, out_cap, n_out, kv_len); API_END
 }
 int svln_engine_stream(svln_engine* h, void** stream) { API_BEGIN_H REQUIRE(stream, "null output pointer"); *stream = h->impl->stream_handle(); API_END }
 int svln_preprocess_time(svln_engine* h, double* gpu_ms, int64_t* frames, int reset) { API_BEGIN_H h->impl->preprocess_time(gpu_ms, frames, reset); API_END }

@@ -77,9 +77,12 @@ class SigLipImageProcessor:
         # the engine writes `out` on its own stream: order the two streams on the device instead of stalling the host twice per frame
         # (the call returns once the frame bytes are staged; svln_encode_frames on the same engine is ordered behind the kernel)
         ext, cur = self._engine_stream(dev), torch.cuda.current_stream(dev)
-        ext.wait_stream(cur)
-        _check(lib.svln_preprocess_frames_enqueue(h, buf.ctypes.data_as(C.c_void_p), n, H, W, 0, C.c_void_p(out.data_ptr())))
-        cur.wait_stream(ext)      # torch work on `out` (and any later reuse of its memory, which stays on this stream) follows the kernel
+        same = cur.cuda_stream == ext.cuda_stream          # the caller runs torch on the engine's stream (model.torch_stream): already ordered
+        if not same:
+            ext.wait_stream(cur)
+        _check(lib.svln_preprocess_frames_enqueue(h, buf.ctypes.data, n, H, W, 0, out.data_ptr()))
+        if not same:
+            cur.wait_stream(ext)  # torch work on `out` (and any later reuse of its memory, which stays on this stream) follows the kernel
         return out
 
     def _engine_stream(self, dev):
@@ -348,12 +351,37 @@ class StreamVLNForCausalLM:
 
     def _order_engine_after(self, pix):
         """The engine's stream is about to read `pix`: order it behind the torch work that produced the tensor (on the device, no host
-        stall)."""
-        self._tower.image_processor._engine_stream(pix.device).wait_stream(torch.cuda.current_stream(pix.device))
+        stall).  Nothing to do when the caller runs torch on the engine's stream (`torch_stream`)."""
+        ext, cur = self._tower.image_processor._engine_stream(pix.device), torch.cuda.current_stream(pix.device)
+        if cur.cuda_stream != ext.cuda_stream:
+            ext.wait_stream(cur)
 
     def _order_torch_after(self, pix):
         """... and the caller's stream behind that read, so that freeing `pix` cannot hand its memory to later torch work too early."""
-        torch.cuda.current_stream(pix.device).wait_stream(self._tower.image_processor._engine_stream(pix.device))
+        ext, cur = self._tower.image_processor._engine_stream(pix.device), torch.cuda.current_stream(pix.device)
+        if cur.cuda_stream != ext.cuda_stream:
+            cur.wait_stream(ext)
+
+    @property
+    def torch_stream(self):
+        """The engine's HIP stream as a torch stream.  A harness that wraps its loop in `with torch.cuda.stream(model.torch_stream):`
+        runs its own tensor ops (stack / to / cat) on the stream the engine uses, so no cross-stream ordering (two event records and
+        two stream waits per frame and per turn) is needed; any other stream works too, at that cost."""
+        return self._tower.image_processor._engine_stream(self.device)
+
+    def frame_ring(self, slots: int, height: int, width: int) -> np.ndarray:
+        """Engine-owned pinned frame ring (svln_frame_ring) as a uint8 array [slots, height, width, 3].  Frames written into a slot and
+        handed to the image processor as that slot's view (`ring[k]`) are read by the GPU in place: no host-side staging copy.  Rewrite
+        a slot only after `frame_ring_wait(k)` (or any call that synchronises, e.g. `generate`'s return for frames preprocessed before)."""
+        base, stride = C.c_void_p(), C.c_int64()
+        _check(self._lib.svln_frame_ring(self._h, int(slots), int(height), int(width), C.byref(base), C.byref(stride)))
+        raw = (C.c_uint8 * (stride.value * slots)).from_address(base.value)
+        arr = np.frombuffer(raw, dtype=np.uint8)
+        self._ring = np.lib.stride_tricks.as_strided(arr, shape=(slots, height, width, 3), strides=(stride.value, width * 3, 3, 1))
+        return self._ring
+
+    def frame_ring_wait(self, slot: int):
+        _check(self._lib.svln_frame_ring_wait(self._h, int(slot)))
 
     @property
     def device(self):
@@ -459,24 +487,48 @@ class StreamVLNForCausalLM:
     @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, depths=None, poses=None, intrinsics=None, task_ids=None,
                  **kwargs):
+        """One model turn = ONE crossing into the engine (svln_turn: encode_rgbd, the KV / embeds bookkeeping of the reference's generate,
+        splice, prefill + greedy decode)."""
         ids, pix, V, n_memory, env_id, past, max_new, eos = self._parse_call(inputs, images, kwargs)
         self._sync_call_config()
+        # the reference's bookkeeping that needs no engine call: the KV handle must be this env's current one; curr_t counts the turns
+        if past is not None and (not isinstance(past, KVHandle) or past.env_id != env_id or past.epoch != self._epoch[env_id]):
+            raise ValueError("past_key_values does not belong to this env's current window")
+        slot = self._slot(env_id)
         on_dev = int(pix.is_cuda)
+        ids_np = ids.numpy()
+        cap = min(max_new, self.cfg.max_positions)
+        buf = self._turn_buffers(cap, eos)
+        a = buf["args"]
+        a.pixels, a.n_frames, a.pixels_on_device, a.env = pix.data_ptr(), V, on_dev, slot
+        a.ids, a.n_ids, a.n_memory = ids_np.ctypes.data, ids_np.size, n_memory
+        a.new_window, a.new_episode, a.max_new_tokens = int(past is None), int(self.curr_t[env_id] == 0), max_new
         if on_dev:
             self._order_engine_after(pix)
-        _check(self._lib.svln_encode_frames(self._h, C.c_void_p(pix.data_ptr()), V, on_dev))
+        rc = self._lib.svln_turn(self._h, buf["args_ref"], buf["out_p"], cap, buf["n_out_ref"], buf["kv_ref"])
         if on_dev:
             self._order_torch_after(pix)
-        self._begin_turn(env_id, past)
-        ids_np = np.ascontiguousarray(ids.numpy())
-        _check(self._lib.svln_append_turn(self._h, self._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
-        cap = min(max_new, self.cfg.max_positions)
-        out = np.zeros(cap, dtype=np.int64)
-        n_out = C.c_int32()
-        eos_np = np.asarray(eos, dtype=np.int64)
-        _check(self._lib.svln_generate(self._h, self._slot(env_id), max_new, eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
-                                       out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n_out)))
-        return self._result(env_id, out[: n_out.value], inputs)
+        _check(rc)
+        self.curr_t[env_id] += 1
+        dev = inputs.device if isinstance(inputs, torch.Tensor) else "cpu"
+        seq = torch.from_numpy(buf["out"][: buf["n_out"].value].copy()).unsqueeze(0)
+        if dev != "cpu" and str(dev) != "cpu":
+            seq = seq.to(dev)
+        return GenerateOutput(sequences=seq, past_key_values=KVHandle(env_id, self._epoch[env_id], buf["kv"].value))
+
+    def _turn_buffers(self, cap, eos):
+        """ctypes scratch of generate(), built once per (capacity, eos list): no per-turn allocation or pointer casting"""
+        key = (cap, tuple(eos))
+        buf = getattr(self, "_tbuf", None)
+        if buf is None or buf["key"] != key:
+            out = np.zeros(cap, dtype=np.int64)
+            eos_np = np.asarray(eos, dtype=np.int64)
+            args = _lib.SvlnTurnArgs()
+            args.eos_ids, args.n_eos = eos_np.ctypes.data, eos_np.size
+            n_out, kv = C.c_int32(), C.c_int32()
+            buf = self._tbuf = {"key": key, "out": out, "out_p": out.ctypes.data_as(C.POINTER(C.c_int64)), "eos": eos_np, "args": args,
+                                "args_ref": C.byref(args), "n_out": n_out, "n_out_ref": C.byref(n_out), "kv": kv, "kv_ref": C.byref(kv)}
+        return buf
 
     @torch.no_grad()
     def generate_batch(self, requests, max_new_tokens: int = 10000, eos_token_ids=None):
@@ -677,8 +729,13 @@ class StreamVLNForCausalLM:
         if getattr(self, "_h", None):
             proc = self._tower.image_processor
             if proc._ext_stream is not None:       # nothing on the torch side may still be ordered against the engine's stream
+                dev = proc._ext_stream.device
                 proc._ext_stream.synchronize()
-                torch.cuda.current_stream(proc._ext_stream.device).synchronize()
+                torch.cuda.current_stream(dev).synchronize()
+                if torch.cuda.current_stream(dev).cuda_stream == proc._ext_stream.cuda_stream:
+                    # the caller adopted the engine's stream (`torch_stream`): it is about to be destroyed, so torch goes back to its
+                    # default stream (a later collective or kernel on a destroyed stream fails with hipErrorInvalidValue)
+                    torch.cuda.set_stream(torch.cuda.default_stream(dev))
                 proc._ext_stream = None
             proc._engine = None
             proc.backend = "closed"

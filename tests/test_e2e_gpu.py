@@ -183,6 +183,77 @@ def test_graph_replay_equals_plain_launches():
         assert np.array_equal(a, b)
 
 
+def test_one_call_turn_equals_the_five_call_sequence_and_stream_adoption():
+    """svln_turn (what `generate` uses: ONE crossing per model turn) against the five entry points it stands for (svln_encode_frames,
+    svln_kv_reset / svln_reset_env, svln_append_turn, svln_generate) driven by hand through the same episode incl. both <memory> restarts:
+    ids, hidden taps, cache lengths and embeds counts bit-identical.  The same episode once more with torch running on the engine's own
+    stream (`model.torch_stream`: no cross-stream ordering calls) and with the frames in the engine's pinned ring."""
+    import ctypes as C
+    from streamvln_amd import _lib
+    from streamvln_amd.synthetic import synthetic_frame
+    sc = SCENARIOS["tiny_episode"]
+    m = _model(sc, torch.bfloat16)
+    log1, taps1 = _run(m, sc)
+    ref = [(r["out"].sequences[0].tolist(), tp["hidden"], tp["cache_len"], tp["n_embeds"]) for r, tp in zip(log1, taps1)]
+
+    class FiveCalls:
+        """the pre-round-4 body of StreamVLNForCausalLM.generate"""
+        def __init__(self, m):
+            self.m = m
+
+        def __getattr__(self, k):
+            return getattr(self.m, k)
+
+        def generate(self, inputs=None, images=None, **kwargs):
+            m = self.m
+            ids, pix, V, n_memory, env_id, past, max_new, eos = m._parse_call(inputs, images, kwargs)
+            m._order_engine_after(pix)
+            _lib.check(m._lib.svln_encode_frames(m._h, pix.data_ptr(), V, 1))
+            m._order_torch_after(pix)
+            m._begin_turn(env_id, past)
+            ids_np = np.ascontiguousarray(ids.numpy())
+            _lib.check(m._lib.svln_append_turn(m._h, m._slot(env_id), ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, n_memory))
+            cap = min(max_new, m.cfg.max_positions)
+            out = np.zeros(cap, dtype=np.int64)
+            n_out = C.c_int32()
+            eos_np = np.asarray(eos, dtype=np.int64)
+            _lib.check(m._lib.svln_generate(m._h, m._slot(env_id), max_new, eos_np.ctypes.data_as(C.POINTER(C.c_int64)), eos_np.size,
+                                            out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n_out)))
+            return m._result(env_id, out[: n_out.value], inputs)
+    m.reset(1)
+    taps = []
+    proc = m.get_vision_tower().image_processor
+    log5 = run_scenario(FiveCalls(m), sc, preprocess=proc.preprocess_array, device="cuda",
+                        on_turn=lambda t, rec: taps.append((m.last_hidden(),) + m.env_state(0)[::-1]))
+    assert len(log5) == len(ref)
+    for t, (rec, (h, kl, ne)) in enumerate(zip(log5, taps)):
+        assert rec["out"].sequences[0].tolist() == ref[t][0], t
+        assert np.array_equal(h, ref[t][1]) and kl == ref[t][2] and ne == ref[t][3], t
+        assert rec["out"].past_key_values.length == kl
+    # torch on the engine's stream + frames in the pinned ring
+    m.reset(1)
+    ring = m.frame_ring(sc["steps"], 480, 640)
+    for s_ in range(sc["steps"]):
+        ring[s_][...] = synthetic_frame(0, s_)
+    slot_of = {synthetic_frame(0, s_).tobytes()[:64]: s_ for s_ in range(sc["steps"])}
+    with torch.cuda.stream(m.torch_stream):
+        log2, taps2 = [], []
+        log2 = run_scenario(m, sc, preprocess=lambda rgb: proc.preprocess_array(ring[slot_of[rgb.tobytes()[:64]]]), device="cuda",
+                            on_turn=lambda t, rec: taps2.append(m.last_hidden()))
+    for t, rec in enumerate(log2):
+        assert rec["out"].sequences[0].tolist() == ref[t][0], t
+        assert np.array_equal(taps2[t], ref[t][1]), t
+    # a stale handle is still refused before anything reaches the engine, and a refused turn does not count
+    ids, img = _first_turn_inputs(m, sc)
+    m.reset(1)
+    out = m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=2, eos_token_ids=[])
+    m.reset_for_env(0)
+    with pytest.raises(ValueError, match="past_key_values"):
+        m.generate(inputs=ids, images=img, env_id=0, time_ids=[[0]], max_new_tokens=2, eos_token_ids=[], past_key_values=out.past_key_values)
+    assert m.curr_t[0] == 0
+    m.close()
+
+
 def test_fp8_decode_weights_opt_in():
     """SURVEY 8f-2 extension (no reference oracle: the reference is bf16 only).  With e4m3 decode weights the prefill is untouched
     (bf16), so every turn's first hidden row is bit-identical; decode-step hidden states stay within the e4m3 error level; graph

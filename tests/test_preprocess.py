@@ -172,3 +172,48 @@ def test_closed_model_processor_raises():
     m.close()
     with pytest.raises(RuntimeError, match="closed"):
         proc.preprocess_array(np.zeros((48, 64, 3), dtype=np.uint8))
+
+
+@pytest.mark.gpu
+def test_frame_ring_is_read_in_place_and_bit_exact():
+    """svln_frame_ring: frames written into the engine's pinned ring and handed over as slot views are read by the GPU where they are
+    (no staging copy) and give the bytes of the staging path / of Pillow; padded slots (frame bytes not a multiple of 256), a
+    multi-frame batch straight from consecutive slots, a pointer inside the ring that is not 16-byte aligned (falls back to staging),
+    slot reuse after svln_frame_ring_wait, and replacing the ring."""
+    import ctypes as C
+    from streamvln_amd import _lib
+    from streamvln_amd.model import StreamVLNForCausalLM
+    m = StreamVLNForCausalLM(TINY, dtype=torch.float32, max_envs=1, max_frames=1, max_positions=256)
+    proc = m.get_vision_tower().image_processor
+    ring = m.frame_ring(6, 480, 640)
+    assert ring.shape == (6, 480, 640, 3) and ring.dtype == np.uint8 and ring.strides[0] == 480 * 640 * 3       # 921 600 = 3600 * 256
+    frames = [synthetic_frame(2, s) for s in range(6)]
+    for k in range(6):
+        ring[k][...] = frames[k]
+    outs = [proc.preprocess_array(ring[k]) for k in range(6)]                     # enqueue-only calls, nothing synchronises in between
+    for k in (0, 3, 5):
+        assert np.array_equal(outs[k].cpu().numpy(), O.siglip_preprocess(frames[k])), k
+    out = torch.empty((3, 3, 384, 384), dtype=torch.float32, device="cuda")       # three consecutive slots as ONE batch, straight from the ring
+    torch.cuda.synchronize()
+    _lib.check(m._lib.svln_preprocess_frames(m._h, ring[2].ctypes.data, 3, 480, 640, 0, out.data_ptr()))
+    for j in range(3):
+        assert np.array_equal(out[j].cpu().numpy(), O.siglip_preprocess(frames[2 + j])), j
+    sub = ring[1].reshape(-1)[3:3 + 48 * 64 * 3].reshape(48, 64, 3)               # inside the ring but 3 bytes off a 16-byte boundary
+    assert np.array_equal(proc.preprocess_array(sub).cpu().numpy(), O.siglip_preprocess(np.array(sub)))
+    m.frame_ring_wait(0)                                                           # the upload that read slot 0 has run: the slot may be rewritten
+    ring[0][...] = frames[5]
+    assert np.array_equal(proc.preprocess_array(ring[0]).cpu().numpy(), O.siglip_preprocess(frames[5]))
+    with pytest.raises(_lib.SvlnError, match="no such slot"):
+        m.frame_ring_wait(6)
+    # a geometry whose frame size is not a multiple of 256 bytes: padded slots
+    ring2 = m.frame_ring(3, 97, 1111)
+    assert ring2.strides[0] % 256 == 0 and ring2.strides[0] >= 97 * 1111 * 3
+    rng = np.random.default_rng(11)
+    odd = [rng.integers(0, 256, (97, 1111, 3), dtype=np.uint8) for _ in range(3)]
+    for k in range(3):
+        ring2[k][...] = odd[k]
+    for k in range(3):
+        assert np.array_equal(proc.preprocess_array(ring2[k]).cpu().numpy(), O.siglip_preprocess(odd[k])), k
+    pv = proc.preprocess(images=[ring2[0], ring2[1]], return_tensors="pt")["pixel_values"]     # (a stacked copy: staging path)
+    assert np.array_equal(pv[1].cpu().numpy(), O.siglip_preprocess(odd[1]))
+    m.close()
