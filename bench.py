@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for rehearsals")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--persistent-decode", action="store_true", help="decode step as attention + ONE persistent launch per layer (svln_set_decode_persistent; "
+                    "measured slower than the six launches at this size, DESIGN.md 4.1: A/B only)")
     ap.add_argument("--pageable-frames", action="store_true", help="camera frames in ordinary numpy arrays instead of the engine's pinned frame ring")
     ap.add_argument("--own-torch-stream", action="store_true", help="leave torch on its default stream (cross-stream ordering per frame / turn) instead of the engine's")
     return ap.parse_args()
@@ -295,6 +297,8 @@ def main():
     model.load_synthetic(a.seed)
     model.model.num_history = NUM_HISTORY
     model.set_decode_graph(not a.no_graph)
+    if a.persistent_decode:
+        model.set_decode_persistent(True)
     run = Runner(model, cfg, rank, frame_ring=not a.pageable_frames)
     if not a.own_torch_stream:
         torch.cuda.set_stream(model.torch_stream)       # the harness's own tensor ops (stack / to) run on the engine's stream: no cross-stream ordering
@@ -483,7 +487,8 @@ def main():
                                    "8-frame window (num_frames 32 / future 4 / history 8), 5 decode tokens/turn, 1 env per GPU; "
                                    "step = one model turn = 4 env steps, each preprocessing its frame (upload + HIP bicubic) inside "
                                    "the timed region", "model_config": a.config, "envs_per_gpu": 1,
-                       "decode_graph": not a.no_graph, "frames": "pageable host arrays" if a.pageable_frames else "engine's pinned frame ring (host)",
+                       "decode_graph": not a.no_graph, "decode_step": "attention + 1 persistent launch per layer" if a.persistent_decode else "6 launches per layer (hipGraph)",
+                       "frames": "pageable host arrays" if a.pageable_frames else "engine's pinned frame ring (host)",
                        "parallelism": f"episode-parallel x{world}",
                        "dist_backend": dist.get_backend() if dist.is_initialized() else None},
             "per_gpu": round(value / world, 2),

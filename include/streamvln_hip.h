@@ -161,6 +161,17 @@ int svln_get_layer_probe(svln_engine* h, int which, float* host_out, int64_t max
 
 /* -- decode execution mode + timing probes (bench.py) */
 int svln_set_decode_graph(svln_engine* h, int enable);     /* replay the per-token decode step as a hipGraph */
+/* Execution form of the single-env decode step (same arithmetic per output, different summation order over K): enable != 0 runs, per
+ * layer, the decode attention launch followed by ONE persistent launch (one workgroup per CU: LDS-DMA weight ring + consumer waves,
+ * granule all-gathers between the products) for the merge of the attention partials, o_proj, gate/up + SwiGLU, down_proj and the next
+ * layer's q|k|v, instead of six launches.  Needs the whole GPU (every workgroup must be resident); a hand-off that times out makes
+ * svln_generate / svln_turn fail.  Refused for shapes it does not cover.  With svln_set_fp8_decode on, the launched GEMVs are kept. */
+int svln_set_decode_persistent(svln_engine* h, int enable);
+/* diagnostic (tools/persist_probe.py): one persistent launch of `layer` with per-workgroup phase stamps, out [n_wgs][16] ticks of the
+ * 100 MHz wall clock: [0] merge done, [1] edge 0 gathered, [2] o_proj done, [3] edge 1 gathered, [4] gate/up done, [5] edge 2 gathered,
+ * [6] down_proj done, [7] edge 3 gathered, [8] q|k|v done (consumer wave 0); [10..14] the loader at the start / after each product's
+ * stream.  Runs on whatever the engine's buffers hold (after a decode step); overwrites the residual row and the q|k|v buffer. */
+int svln_probe_decode_layer(svln_engine* h, int layer, unsigned long long* out, int max_wgs, int32_t* n_wgs);
 /* Opt-in, no reference counterpart: the single-env decode step and the lm_head stream OCP e4m3 copies of the LLM
  * weights (one fp32 scale per output row, quantised on the device from the loaded tensors at the first enable) instead of the bf16
  * ones -- half the HBM bytes per generated token.  bf16 engines only; prefill, vision and svln_generate_batch keep bf16 weights. */

@@ -82,6 +82,8 @@ SIGNATURES = {
     "svln_get_layer_taps": (_I, [_P, _PF]),
     "svln_get_layer_probe": (_I, [_P, _I, _PF, _I64, _PI32, _PI32]),
     "svln_set_decode_graph": (_I, [_P, _I]),
+    "svln_set_decode_persistent": (_I, [_P, _I]),
+    "svln_probe_decode_layer": (_I, [_P, _I, C.POINTER(C.c_uint64), _I, _PI32]),
     "svln_set_fp8_decode": (_I, [_P, _I]),
     "svln_set_fp8_gemm": (_I, [_P, _I]),
     "svln_set_memory_prune": (_I, [_P, _I]),

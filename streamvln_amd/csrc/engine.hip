@@ -97,6 +97,8 @@ struct EngineBase {
     virtual void get_top2(float* out) = 0;
     virtual void sync() = 0;
     virtual void set_graph(int enable) = 0;
+    virtual void set_decode_persistent(int enable) = 0;
+    virtual void probe_decode_layer(int layer, unsigned long long* out, int max_wgs, int32_t* n_wgs) = 0;
     virtual void set_fp8_decode(int enable) = 0;
     virtual void set_fp8_gemm(int enable) = 0;
     virtual bool op_gemm_fp8(const GemmArgs& a) = 0;
@@ -386,6 +388,7 @@ public:
         for (auto e : pprobe_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ph_ev[i]);
         (void)hipHostFree(h_ctl); (void)hipHostFree(h_out_ids);
+        if (h_giveup) (void)hipHostFree(h_giveup);
         if (h_hash) (void)hipHostFree(h_hash);
         for (void* p : allocs) (void)hipFree(p);
         (void)hipHostFree(h_src); (void)hipHostFree(h_token); (void)hipHostFree(h_top2);
@@ -944,14 +947,75 @@ public:
     // One decode step as a fixed op sequence; every run-time scalar is read from device memory (d_ctl,
     // d_token) so any sub-range [lo, hi) of the sequence can be captured once and graph-replayed.
     // Op ids: 0 = embedding gather, then 6 per layer (qkv GEMV, attention with fused RoPE + KV append, combine, o GEMV,
-    // gate/up GEMV, down GEMV); the layer-0 gate/up GEMV is op PROBE_OP.
-    static constexpr int OPS_PER_LAYER = 6, PROBE_OP = 1 + 4;
-    int total_ops() const { return 1 + c.layers * OPS_PER_LAYER; }
+    // gate/up GEMV, down GEMV); the layer-0 gate/up GEMV is op probe_op().
+    static constexpr int OPS_PER_LAYER = 6;
+    // Persistent decode layer (svln_set_decode_persistent; decode_layer.hip): per layer the attention launch + ONE launch for everything
+    // behind it (merge of the partials, o_proj, gate/up, down_proj, the next layer's q|k|v), instead of six launches.
+    bool persistent_on = false; int n_cus = 0;
+    unsigned long long* dl_gran[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned* dl_seq = nullptr; unsigned* dl_giveup = nullptr; unsigned* h_giveup = nullptr;
+    DecodeLayerArgs layer_args(int i) {
+        const LLayer& L = ll[i];
+        DecodeLayerArgs a; std::memset(&a, 0, sizeof(a));
+        a.part = attn_part; a.nsplit = nsplit_max; a.tiles_per_split = tiles_per_split; a.dyn_kv_len = &d_ctl->kv_len; a.n_kv = nkv; a.Gq = nq / nkv;
+        a.o_w = L.o_w; a.post_norm = L.post_norm; a.gu_w = L.gu_w; a.down_w = L.down_w;
+        if (i + 1 < c.layers) { a.next_norm = ll[i + 1].in_norm; a.next_qkv_w = ll[i + 1].qkv_w; a.next_qkv_b = ll[i + 1].qkv_b; }
+        a.x = x; a.qkv_out = qkv; a.H = H; a.I = I; a.qd = nq * 128; a.qkv_dim = qkv_dim; a.eps = c.rms_eps;
+        for (int k = 0; k < 4; ++k) a.gran[k] = dl_gran[k];
+        a.seq = dl_seq; a.giveup = dl_giveup; a.skip = &d_ctl->done;
+        return a;
+    }
+    void set_decode_persistent(int enable) override {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (!enable) { if (persistent_on) drop_graphs(); persistent_on = false; return; }
+        if (!n_cus) { hipDeviceProp_t pr; HIP_CHECK(hipGetDeviceProperties(&pr, device)); n_cus = pr.multiProcessorCount; }
+        DecodeLayerArgs a = layer_args(0);
+        REQUIRE(decode_layer_supported<T>(a, n_cus), "persistent decode layer: this configuration is not supported (per-CU slices of hidden / inter / q|k|v "
+                                                   "must be whole, rows whole KiB, LDS <= 160 KiB)");
+        if (!dl_seq) {
+            const size_t ng[4] = {(size_t)nq * 128, (size_t)H, (size_t)I, (size_t)H};
+            for (int k = 0; k < 4; ++k) dl_gran[k] = dalloc<unsigned long long>(ng[k], true);
+            dl_seq = dalloc<unsigned>(64, true);          // [0] = launch counter, [16] = give-up word (own cache lines)
+            dl_giveup = dl_seq + 16;
+            HIP_CHECK(hipHostMalloc((void**)&h_giveup, 64));
+            h_giveup[0] = 0;
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (!persistent_on) drop_graphs();
+        persistent_on = true;
+    }
+    // diagnostic: ONE persistent launch of `layer` on whatever the buffers hold after the last decode step, with phase stamps per workgroup
+    void probe_decode_layer(int layer, unsigned long long* out, int max_wgs, int32_t* n_wgs) override {
+        REQUIRE(persistent_on && layer >= 0 && layer < c.layers, "persistent decode layer is off / no such layer");
+        unsigned long long* d = nullptr;
+        HIP_CHECK(hipMalloc((void**)&d, (size_t)n_cus * 16 * 8));
+        HIP_CHECK(hipMemsetAsync(d, 0, (size_t)n_cus * 16 * 8, st));
+        DecodeLayerArgs a = layer_args(layer);
+        a.skip = nullptr; a.dbg = d;
+        launch_decode_layer<T>(st, a, n_cus);
+        const int n = n_cus < max_wgs ? n_cus : max_wgs;
+        HIP_CHECK(hipMemcpyAsync(out, d, (size_t)n * 16 * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipFree(d));
+        *n_wgs = n;
+    }
+    bool persistent_active() const { return persistent_on && !fp8_on; }       // (the e4m3 decode weights keep the launched GEMVs)
+    int probe_op() const { return persistent_active() ? 3 : 1 + 4; }          // the launch the roofline probe times (layer 0)
+    int total_ops() const { return persistent_active() ? 2 + 2 * c.layers : 1 + c.layers * OPS_PER_LAYER; }
     void decode_ops(Env& e, int lo, int hi) {
         const int qd = nq * 128;
         int op = 0;
         auto on = [&](void) { const bool r = op >= lo && op < hi; ++op; return r; };
         if (on()) launch_gather_rows<T>(st, d_token, embed, feats, x, 1, H, &d_ctl->done);
+        if (persistent_active()) {
+            // op 1: layer 0's q|k|v rows; then per layer: decode attention (RoPE, KV append, per-page partials), the persistent layer
+            if (on()) launch_gemv<T>(st, guarded(gemv_args(ll[0].qkv_w, H, x, ll[0].in_norm, ll[0].qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE)));
+            for (int i = 0; i < c.layers; ++i) {
+                AttnArgs a = llm_attn_args(ll[i], e, qkv, qkv_dim, attn, qd, 1, 0, 0, true);
+                if (on()) launch_attention<T>(st, a, 128, 1);
+                if (on()) launch_decode_layer<T>(st, layer_args(i), n_cus);
+            }
+            return;
+        }
         for (int i = 0; i < c.layers; ++i) {
             const LLayer& L = ll[i];
             if (on()) launch_gemv<T>(st, guarded(with8(gemv_args(L.qkv_w, H, x, L.in_norm, L.qkv_b, nullptr, qkv, qkv_dim, H, EPI_NONE), L.qkv8)));
@@ -967,8 +1031,9 @@ public:
     // layer-0 gate/up SwiGLU GEMV with the kernel's own begin/end timestamps
     void probe_launch(Env&) {
         const LLayer& L = ll[0];
-        launch_gemv_timed<T>(st, guarded(with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8)), probe_ev[probe_used],
-                             probe_ev[probe_used + 1]);
+        if (persistent_active()) launch_decode_layer<T>(st, layer_args(0), n_cus, probe_ev[probe_used], probe_ev[probe_used + 1]);
+        else launch_gemv_timed<T>(st, guarded(with8(gemv_args(L.gu_w, H, x, L.post_norm, nullptr, nullptr, hbuf, 2 * I, H, EPI_SWIGLU), L.gu8)), probe_ev[probe_used],
+                                  probe_ev[probe_used + 1]);
         probe_used += 2;
     }
     // graph of: ops [lo, hi) of one decode step (+ the head when hi is the end of the step), then `more` further whole steps
@@ -1027,9 +1092,9 @@ public:
             if (!probing) {
                 HIP_CHECK(hipGraphLaunch(get(steps, 0, n_ops, steps - 1), st));
             } else {
-                HIP_CHECK(hipGraphLaunch(get(1000, 0, PROBE_OP, 0), st));
+                HIP_CHECK(hipGraphLaunch(get(1000, 0, probe_op(), 0), st));
                 probe_launch(e);
-                HIP_CHECK(hipGraphLaunch(get(2000 + steps, PROBE_OP + 1, n_ops, steps - 1), st));
+                HIP_CHECK(hipGraphLaunch(get(2000 + steps, probe_op() + 1, n_ops, steps - 1), st));
             }
             return;
         }
@@ -1037,9 +1102,9 @@ public:
             if (!(probing && k == 0)) {
                 decode_ops(e, 0, n_ops);
             } else {
-                decode_ops(e, 0, PROBE_OP);
+                decode_ops(e, 0, probe_op());
                 probe_launch(e);
-                decode_ops(e, PROBE_OP + 1, n_ops);
+                decode_ops(e, probe_op() + 1, n_ops);
             }
             head(x, first_tap_row + k, true);
         }
@@ -1437,8 +1502,17 @@ public:
             HIP_CHECK(hipMemcpyAsync(h_ctl, d_ctl, sizeof(GenCtl), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipMemcpyAsync(h_out_ids, d_out_ids, (size_t)enq * sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipMemcpyAsync(h_top2, d_top2, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (persistent_on) HIP_CHECK(hipMemcpyAsync(h_giveup, dl_giveup, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             LAUNCH_CHECK("generate");
+            if (persistent_on && h_giveup[0]) {
+                const unsigned code = h_giveup[0];
+                h_giveup[0] = 0;
+                HIP_CHECK(hipMemsetAsync(dl_giveup, 0, sizeof(unsigned), st));
+                char msg[200];
+                snprintf(msg, sizeof(msg), "persistent decode layer: a hand-off wait timed out (code 0x%x); the turn's results are invalid (is another process using the GPU?)", code);
+                REQUIRE(false, msg);
+            }
             n = h_ctl->count;
             done = h_ctl->done != 0;
             REQUIRE(n >= 1 && n <= enq, "generation state out of range");
@@ -1629,6 +1703,8 @@ public:
         if (pprobe_ev.empty()) { pprobe_ev.resize(512); for (auto& ev : pprobe_ev) HIP_CHECK(hipEventCreate(&ev)); }
         probe_used = 0; probe_on = true; pprobe_used = 0; pprobe_rows = 0;
         probe_bytes = (double)2 * I * H * sizeof(T);
+        // persistent layer: the four products one launch streams (o, gate/up, down, the next layer's q|k|v)
+        if (persistent_active()) probe_bytes = ((double)H * nq * 128 + (double)2 * I * H + (double)H * I + (double)qkv_dim * H) * sizeof(T);
     }
     void probe_read(double* ms, int64_t* launches, double* bytes) override {
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1836,6 +1912,10 @@ int svln_get_embeds(svln_engine* h, int env, int start, int n, float* out) { API
 int svln_get_frame_feats(svln_engine* h, int start, int n, float* out) { API_BEGIN_H h->impl->get_feats(start, n, out); API_END }
 int svln_get_top2(svln_engine* h, float* out) { API_BEGIN_H h->impl->get_top2(out); API_END }
 int svln_set_decode_graph(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_graph(enable); API_END }
+int svln_set_decode_persistent(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_decode_persistent(enable); API_END }
+int svln_probe_decode_layer(svln_engine* h, int layer, unsigned long long* out, int max_wgs, int32_t* n_wgs) {
+    API_BEGIN_H REQUIRE(out && n_wgs, "null output pointer"); h->impl->probe_decode_layer(layer, out, max_wgs, n_wgs); API_END
+}
 int svln_set_fp8_decode(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_fp8_decode(enable); API_END }
 int svln_set_fp8_gemm(svln_engine* h, int enable) { API_BEGIN_H h->impl->set_fp8_gemm(enable); API_END }
 int svln_set_memory_prune(svln_engine* h, int keep_tokens) { API_BEGIN_H h->impl->set_memory_prune(keep_tokens); API_END }

@@ -164,6 +164,26 @@ struct AttnArgs {
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves);
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);
 
+// Persistent batch-1 decode layer (decode_layer.hip): merge of this layer's split-KV attention partials, o_proj + residual,
+// post_attention_layernorm, gate/up + SwiGLU, down_proj + residual, and the NEXT layer's input_layernorm + q|k|v projection, as ONE launch
+// of one workgroup per CU (LDS-DMA loader ring + consumer waves, data-tagged granule all-gathers between the products).
+struct DecodeLayerArgs {
+    const float* part; int nsplit, tiles_per_split; const int* dyn_kv_len; int n_kv, Gq;      // attn_decode_kernel's partials [split][n_kv][32][132]
+    const void *o_w, *post_norm, *gu_w, *down_w;                                            // this layer (engine dtype, packed as the engine holds them)
+    const void *next_norm, *next_qkv_w, *next_qkv_b;                                        // next layer's input_layernorm / q|k|v; null for the last layer
+    void* x;                      // residual stream [H]: read at the start, rewritten with the layer's output
+    void* qkv_out;                // [qkv_dim]: the next layer's q | k | v rows (bias added, un-roped)
+    int H, I, qd, qkv_dim; float eps;
+    unsigned long long* gran[4];  // granule buffers of the four all-gather edges (qd, H, I, H values)
+    unsigned* seq;                // launch counter (device): the epoch of the launch's granule tags
+    unsigned* giveup;             // != 0: a bounded spin timed out (code); results are invalid
+    const int* skip;              // optional device flag: no-op when *skip != 0 (run-ahead steps past the end of the generation)
+    unsigned long long* dbg;      // optional [workgroups][16] phase stamps (100 MHz clock): svln_probe_decode_layer
+};
+template <typename T> bool decode_layer_supported(const DecodeLayerArgs& a, int cus);
+template <typename T> void launch_decode_layer(hipStream_t s, const DecodeLayerArgs& a, int cus, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+void decode_layer_init_attrs();
+
 // RMSNorm / LayerNorm over rows of length n (T in, T out).
 // y2 / y2_row / y2_cap: optional second copy of the rows at row *y2_row (device scalar) of y2, clamped to y2_cap rows
 template <typename T> void launch_rmsnorm(hipStream_t s, const void* x, const void* g, void* y, int rows, int n, float eps, const int* skip = nullptr,
@@ -248,7 +268,7 @@ void gemv_init_attrs();
 void attention_init_attrs();
 inline hipError_t init_kernel_attributes() {
     attr_status() = hipSuccess;
-    gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); preprocess_init_attrs();
+    gemm_init_attrs(); gemv_init_attrs(); attention_init_attrs(); preprocess_init_attrs(); decode_layer_init_attrs();
     return attr_status();
 }
 

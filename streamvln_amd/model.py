@@ -707,6 +707,10 @@ class StreamVLNForCausalLM:
     def set_decode_graph(self, enable: bool):
         _check(self._lib.svln_set_decode_graph(self._h, int(enable)))
 
+    def set_decode_persistent(self, enable: bool):
+        """single-env decode step as attention + ONE persistent launch per layer (svln_set_decode_persistent) instead of six launches"""
+        _check(self._lib.svln_set_decode_persistent(self._h, int(enable)))
+
     def set_memory_prune(self, keep_tokens: int):
         """Opt-in extension (BASELINE configs[3]; no reference counterpart): `<memory>` expands to the `keep_tokens`
         memory tokens least similar to the mean memory token instead of all num_history x 196.  0 restores the reference behaviour."""
