@@ -330,13 +330,18 @@ def main():
         if n.value:
             avg_s = ms.value / n.value / 1e3
             ach = by.value / avg_s / 1e9
-            traffic = None          # HBM bytes/launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
+            # HBM bytes/launch: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes (tools/make_profiles.sh);
+            # the value is read from the latest committed pass of this kernel (gfx950 FETCH_SIZE x2 correction) and its file is named
+            traffic = traffic_src = None
             import glob
-            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemv_swiglu_pmc.json")))      # the latest round's PMC passes of this kernel
-            if pmcs and a.config == "streamvln_qwen2_7b" and a.dtype == "bf16":
+            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemv_swiglu_pmc.json")))
+            if pmcs and a.config == "streamvln_qwen2_7b" and a.dtype == "bf16" and not a.persistent_decode:
                 traffic = json.load(open(pmcs[-1]))["traffic_bytes_per_launch"]
-            roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)", "achieved": round(ach, 1),
-                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                traffic_src = os.path.relpath(pmcs[-1], ROOT)
+            kern = ("decode_layer_kernel<bf16> (persistent layer: o_proj + gate/up + down_proj + next q|k|v)" if a.persistent_decode
+                    else "gemv_kernel<bf16, EPI_SWIGLU> (decode gate/up projection)")
+            roof = {"bound": "hbm", "kernel": kern, "achieved": round(ach, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": by.value, "avg_us": round(avg_s * 1e6, 2), "launches_timed": n.value}
 
     roof2 = None
@@ -423,7 +428,17 @@ def main():
             if n < len(ia):
                 break
         fp8["vs_bf16"] = {"ids_agree_before_first_divergence": f"{agree}/{total}", "hidden_rel_l2_worst": round(worst, 4),
-                          "sample": "first 3 turns of an episode, 5 tokens each, same frames and prompts"}
+                          "sample": "first 3 turns of an episode, 5 tokens each, same frames and prompts (the distance to bf16 is the e4m3 scheme's own "
+                                    "noise on random-init weights, not an error bound: DESIGN.md 6)"}
+        # engine vs the SAME numeric scheme restated on the CPU (oracle Fp8Emu): measured by tests/test_fp8_gpu.py on the GPU box and committed;
+        # bench.py does not run the oracle for this (only its cpu_baseline leg may)
+        import glob
+        emu = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fp8_vs_emulation.json")))
+        if emu and a.config == "streamvln_qwen2_7b":
+            e = json.load(open(emu[-1]))
+            fp8["vs_emulation"] = {"source": os.path.relpath(emu[-1], ROOT),
+                                   "decode_weights_full_depth": e.get("streamvln_qwen2_7b/decode"),
+                                   "mfma_products_full_depth": {k: v for k, v in (e.get("streamvln_qwen2_7b/gemm") or {}).items() if k != "depth_curve_vs_bf16_engine"}}
     # opt-in slow-memory pruning (BASELINE configs[3] "32 pruned slow-memory tokens"; no reference counterpart, SURVEY a-13).
     pruned = None
     if not a.no_prune_pass:

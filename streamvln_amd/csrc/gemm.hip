@@ -3,25 +3,29 @@
 //
 // gemm_glds_kernel: MFMA 32x32 accumulators, MI x NJ of them per wave; both operands staged straight into LDS by LDS-DMA
 // (global_load_lds_dwordx4) through a ring of stage buffers (one stage = 128 B of K per tile row), fragment reads by
-// inline-asm ds_read_b128, one s_barrier per stage.  Three tile configurations, picked in launch_epi from M, N:
+// inline-asm ds_read_b128, one s_barrier per stage.  Tile configurations, picked in launch_epi from M, N, K:
 //   * Cfg256  256x128, 8 waves (64x64 wave tiles), 3-deep ring, split-K over the grid  -- M <= 256 (steady prefill T ~ 212,
 //     one-frame ViT 729 rows with few column tiles): the whole M extent sits in one row tile so every weight byte is
 //     streamed from HBM once, and K is split so that about one workgroup per CU exists.  Split-K partials go to fp32 slabs
 //     [split][M][N]; a second launch sums them and applies the epilogue (splitk_epilogue_kernel), or -- for o_proj /
 //     down_proj / SigLIP out_proj / fc2 -- also the following RMSNorm / LayerNorm (splitk_rownorm_kernel).
-//   * Cfg128  128x128, 4 waves, 2-deep ring, two workgroups per CU                      -- mid-size M
-//   * CfgBig  256x256, 8 waves (128x64 wave tiles), 2-deep ring                         -- >= 256 such tiles (T ~ 1952,
-//     batched-env prefill, 9-frame ViT)
-// gemm_nt_kernel is the older register-staged form (global -> VGPR -> LDS), kept for callers without a zero line and as a
-// cross-check in the tests (force_cfg | 0x2000).
+//   * Cfg128 / Cfg128L  128x128, 4 waves, 2-deep ring, two workgroups per CU            -- mid-size M; Cfg128K2: the same tile with two
+//     K-groups of 4 waves inside the workgroup (one-frame ViT q|k|v / fc1, projector)
+//   * Cfg256N64  256x64, 8 waves stacked along M, 3-deep ring, split-K                  -- q|k|v and o_proj of a steady prefill
+//   * CfgBig  256x256, 8 waves (128x64 wave tiles), 2-deep stage ring (fp8 / fp32 operands); Cfg8P: the same tile on the 8-phase
+//     schedule with 16x16x32 MFMAs (bf16 operands)                                      -- >= 140 such tiles (T ~ 1952, batched-env
+//     prefill, 9-frame ViT); with two K slices for long-K products of 96-128 tiles (window-restart down_proj)
+//   * CfgSkinny  32x128, 2 waves                                                        -- M <= 32 (envs decoded in lockstep)
+//   * Cfg64  64x64 (force_cfg only)
 // LDS rows are 128 B: the 16-byte chunk index is XOR-swizzled with the row bits above the 256-byte bank row so the 16 lanes
 // of every ds_read_b128 group hit 16 distinct 16-byte slots (the swizzle is applied on the DMA's source address).
 // Workgroup ids are remapped so that each of the 8 XCDs owns a contiguous band of tiles (operand panels shared through the
 // XCD's private L2).
 //
-// Roofline: MFMA for M >= ~512 (measured 770-990 TF/s, MFMA pipe busy ~45 %: one stage in flight per CU); at M ~ 212 the L2 -> LDS path
-// (t_stage ~ W_bytes / 6 TB/s + A_bytes / 22.7 TB/s).
+// Roofline: MFMA for M >= ~512 (measured 1.0-1.1 PF/s on the 8-phase kernel, MFMA pipe busy 55-60 %); at M ~ 212 the per-CU stream rate
+// (a CU keeps ~64 lines of 128 B in flight: stage ~ W_bytes / 17 GB/s + A_bytes / 69 GB/s per CU).
 // Algorithmic flops = 2*M*N*K, algorithmic bytes = (M*K + N*K + M*N) * sizeof(T).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -65,6 +69,8 @@ using Cfg64 = TileCfg<64, 64, 2, 1, 128, false, 6>;          // 64x64, 2 waves (
                                                              // products with few 128-wide column tiles and a short K (force_cfg 64 only, see launch_epi)
 using Cfg128K2 = TileCfg<128, 128, 2, 2, 128, false, 2, false, 2>;   // 128x128 tile, 2 K-groups of 4 waves (128 KB of LDS: one workgroup per CU): one-round launches with a
                                                              // short K and an epilogue that wants the finished value (one-frame ViT qkv / fc1, projector)
+using Cfg256N64 = TileCfg<256, 64, 8, 1, 128, true, 3>;       // 256x64, 8 waves stacked along M (32 x 64 wave tiles): the CDNA guide's tile for M = 256 projections
+                                                             // (force_cfg 264 only: measured inside the turn against 256x128 x split-K)
 using CfgSkinny = TileCfg<32, 128, 1, 2, 128, false, 3>;     // M <= 32 (lockstep decode of several envs): 2 waves, 20 KB stages, glds kernel only
 
 template <typename C> SVLN_DEV int swz(int row, int c) { return (c ^ ((row >> C::SH) & (C::CH - 1))) << 4; }
@@ -75,195 +81,6 @@ template <typename T, int EPI> SVLN_DEV float epi_act(float v) {
     if (EPI == EPI_GELU_TANH) return gelu_tanh_f(v);
     if (EPI == EPI_GELU_ERF) return gelu_erf_f(v);
     return v;
-}
-
-template <typename T, int EPI, typename C, bool SPLITK>
-__global__ __launch_bounds__(C::THREADS) void gemm_nt_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int EPC = Elt<T>::PER_CHUNK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / C::WN, wc = wave % C::WN;
-    const int r32 = lane & 31, h = lane >> 5;
-
-    const int tiles_m = (p.M + C::BM - 1) / C::BM;
-    const int nsplit = SPLITK ? p.nsplit : 1;
-    const int nwg = p.launch_tiles * nsplit;            // p.launch_tiles = (row tiles) x (column tiles of THIS launch)
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap (blocks b, b+8, ... share an XCD): give each XCD a contiguous band
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    // order: row tile fastest (they share the W panel), then K split, then column tile
-    const int bm = bid % tiles_m;
-    const int ks = (bid / tiles_m) % nsplit;
-    const int bn = p.tile_base + bid / (tiles_m * nsplit);
-    const int row0 = bm * C::BM, col0 = bn * C::BN;
-    const int kchunks = p.K / EPC;
-    const int stages_total = (kchunks + C::CH - 1) / C::CH;
-    const int stages_per = (stages_total + nsplit - 1) / nsplit;
-    const int st_begin = ks * stages_per;
-    const int st_end = min(stages_total, st_begin + stages_per);
-
-    const T* A = (const T*)p.A;
-    const T* W = (const T*)p.W;
-    const bool w_nt = tiles_m == 1;
-
-    struct Regs { uint4 a[C::A_LOADS]; uint4 w[C::W_LOADS]; };
-    auto load_stage = [&](Regs& rg, int st) {
-#pragma unroll
-        for (int i = 0; i < C::A_LOADS; ++i) {
-            const int q = tid + C::THREADS * i, r = q / C::CH, kc = st * C::CH + (q % C::CH);
-            const int gr = row0 + r;
-            rg.a[i] = (gr < p.M && kc < kchunks) ? *(const uint4*)(A + (size_t)gr * p.lda + (size_t)kc * EPC) : zero_chunk();
-        }
-#pragma unroll
-        for (int i = 0; i < C::W_LOADS; ++i) {
-            const int q = tid + C::THREADS * i, r = q / C::CH, kc = st * C::CH + (q % C::CH);
-            const int gc = col0 + r;
-            // a weight panel that only ONE row tile reads is a read-once stream: non-temporal, so it does not evict
-            // the activation panel (re-read by every column tile) from the XCD's L2
-            if (gc < p.N && kc < kchunks) {
-                const T* src = W + (size_t)gc * p.ldw + (size_t)kc * EPC;
-                rg.w[i] = w_nt ? load_nt(src) : *(const uint4*)src;
-            } else {
-                rg.w[i] = zero_chunk();
-            }
-        }
-    };
-    auto store_stage = [&](const Regs& rg, int buf) {
-        char* sa = smem + buf * C::STAGE_BYTES;
-        char* sw = sa + C::BM * C::ROWB;
-#pragma unroll
-        for (int i = 0; i < C::A_LOADS; ++i) {
-            const int q = tid + C::THREADS * i, r = q / C::CH, c = q % C::CH;
-            *(uint4*)(sa + r * C::ROWB + swz<C>(r, c)) = rg.a[i];
-        }
-#pragma unroll
-        for (int i = 0; i < C::W_LOADS; ++i) {
-            const int q = tid + C::THREADS * i, r = q / C::CH, c = q % C::CH;
-            *(uint4*)(sw + r * C::ROWB + swz<C>(r, c)) = rg.w[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    auto compute = [&](int buf) {
-        const char* sa = smem + buf * C::STAGE_BYTES;
-        const char* sw = sa + C::BM * C::ROWB;
-#pragma unroll
-        for (int s = 0; s < C::CH / 2; ++s) {
-            uint4 a[2], b[2];
-            const int c = 2 * s + h;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wr * 64 + i * 32 + r32;
-                a[i] = *(const uint4*)(sa + r * C::ROWB + swz<C>(r, c));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wc * 64 + j * 32 + r32;
-                b[j] = *(const uint4*)(sw + r * C::ROWB + swz<C>(r, c));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma_chunk<T>(a[i], b[j], acc[i][j]);
-        }
-    };
-
-    const int n = st_end - st_begin;
-    if (n > 0) {
-        if (C::DEEP) {
-            // two register sets: while stage t is consumed from LDS, stage t+1 is landing in one set and stage t+2 has
-            // just been issued into the other (two stages of HBM latency tolerance with two LDS buffers)
-            Regs r0, r1;
-            load_stage(r0, st_begin);
-            if (n > 1) load_stage(r1, st_begin + 1);
-            store_stage(r0, 0);
-            __syncthreads();
-            for (int i = 0; i < n; i += 2) {
-                if (i + 2 < n) load_stage(r0, st_begin + i + 2);
-                compute(0);
-                if (i + 1 < n) store_stage(r1, 1);
-                __syncthreads();
-                if (i + 1 >= n) break;
-                if (i + 3 < n) load_stage(r1, st_begin + i + 3);
-                compute(1);
-                if (i + 2 < n) store_stage(r0, 0);
-                __syncthreads();
-            }
-        } else {
-            Regs r0;
-            load_stage(r0, st_begin);
-            store_stage(r0, 0);
-            __syncthreads();
-            for (int i = 0; i < n; ++i) {
-                const bool more = i + 1 < n;
-                if (more) load_stage(r0, st_begin + i + 1);
-                compute(i & 1);
-                if (more) store_stage(r0, (i & 1) ^ 1);
-                __syncthreads();
-            }
-        }
-    }
-
-    // D[row = A row][col = W row]; lanes 0..31 hold 32 consecutive columns
-    if (SPLITK) {
-        float* slab = p.ws + (size_t)ks * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = col0 + wc * 64 + j * 32 + r32;
-                if (n >= p.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
-                    if (m < p.M) slab[(size_t)m * p.N + n] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    T* Cc = (T*)p.C;
-    const T* bias = (const T*)p.bias;
-    const T* res = (const T*)p.res;
-    if (EPI == EPI_SWIGLU) {
-        const int n_out = ((col0 + wc * 64) >> 1) + r32;
-        const bool ok_n = (col0 + wc * 64 + 32 + r32) < p.N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
-                if (m < p.M && ok_n) Cc[(size_t)m * p.ldc + n_out] = from_f32<T>(silu_f(acc[i][0][r]) * acc[i][1][r]);
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = col0 + wc * 64 + j * 32 + r32;
-            if (n >= p.N) continue;
-            const float bv = bias ? to_f32(bias[n]) : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wr * 64 + i * 32 + acc_row(r, lane);
-                if (m >= p.M) continue;
-                float v = epi_act<T, EPI>(acc[i][j][r] + bv);
-                if (res) {
-                    const int rr = p.res_mod > 0 ? m % p.res_mod : m;
-                    v += to_f32(res[(size_t)rr * p.ldr + n]);
-                }
-                Cc[(size_t)m * p.ldc + n] = from_f32<T>(v);
-            }
-        }
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1172,35 +989,39 @@ __global__ __launch_bounds__(256) void splitk_qkv_vitpack_kernel(GemmArgs p, Vit
     }
 }
 
+// EVERY launch of gemm_glds_kernel goes through here: the block size and the dynamic-LDS size come from the same TileCfg as the kernel
+// instantiation (its __launch_bounds__ and its LDS carve), so a geometry the code object cannot take -- which hipLaunchKernel does not
+// report: the packet processor rejects the dispatch and the runtime aborts the process (the round-2 test_gemm abort) --
+// cannot be written at a call site.  gemm_init_attrs() registers the same pairs with set_max_lds, which checks them against the code
+// object's attributes at engine creation.
+template <typename T, int EPI, typename C, bool SPLITK, typename TA = T, bool NTW = false, bool VP = false>
+void launch_tile(hipStream_t s, const GemmArgs& a, int wgs) {
+    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, TA, NTW, VP>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+}
+
 template <typename T, int EPI, typename C, bool SPLITK> void launch_cfg(hipStream_t s, const GemmArgs& a, int nsplit) {
     const int wgs = a.launch_tiles * nsplit;
     if (wgs <= 0) return;
-    if constexpr (C::MI == 2 && C::NJ == 2 && C::KG == 1) {
-        if ((!a.zeros || (a.force_cfg & 0x2000)) && !a.a_scale) {          // register-staged kernel (64x64 wave tiles only; bf16 / fp32 operands)
-            hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), 2 * C::STAGE_BYTES, s, a);
-            return;
-        }
-    }
-    constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value;      // the single-row-tile configurations
+    constexpr bool HAS_NTW = std::is_same<C, Cfg256>::value || std::is_same<C, CfgSkinny>::value || std::is_same<C, Cfg256N64>::value;      // the single-row-tile configurations
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_SWIGLU)) {
         if (a.a_scale) {                                   // e4m3 operands (opt-in; the LLM linears: plain and SwiGLU epilogues)
             if constexpr (HAS_NTW) {
                 if (a.nt_w) {
-                    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+                    launch_tile<T, EPI, C, SPLITK, fp8_t, true>(s, a, wgs);
                     return;
                 }
             }
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, fp8_t>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+            launch_tile<T, EPI, C, SPLITK, fp8_t>(s, a, wgs);
             return;
         }
     }
     if constexpr (HAS_NTW) {
         if (a.nt_w) {
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK, T, true>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+            launch_tile<T, EPI, C, SPLITK, T, true>(s, a, wgs);
             return;
         }
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, C, SPLITK>), dim3(wgs), dim3(C::THREADS), C::LDS_BYTES, s, a);
+    launch_tile<T, EPI, C, SPLITK>(s, a, wgs);
 }
 
 // sum the split-K slabs and apply the epilogue (returns true when the reduce also emitted the following norm / the fused tail)
@@ -1261,7 +1082,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     //   episode) the second one is mostly padding: 128x128 tiles take its gate/up from 192 to ~140 us (prefill of that turn 10.5 -> 9.0 ms)
     // M <= 32 (several envs decoded in lockstep): 32x128 tiles, 2 waves, three 20 KB stages in flight per workgroup and two
     // workgroups per CU -- a weight stream through LDS-DMA with 4 MFMAs per stage, K split when there are few column tiles
-    if (a.M <= 32 && a.zeros && !(a.force_cfg & 0x2000) && ((a.force_cfg & 0xFFF) == 0 || (a.force_cfg & 0xFFF) == 32)) {
+    if (a.M <= 32 && ((a.force_cfg & 0xFFF) == 0 || (a.force_cfg & 0xFFF) == 32)) {
         const int tiles_n = (a.N + 127) / 128;
         const int stages = (a.K / EPC + CfgSkinny::CH - 1) / CfgSkinny::CH;
         const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
@@ -1289,7 +1110,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
             a.zeros && !a.a_scale && can_split) {
             a.nsplit = 2;
             a.launch_tiles = tilesbig;
-            hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, Cfg8P, true>), dim3(tilesbig * 2), dim3(Cfg8P::THREADS), Cfg8P::LDS_BYTES, s, a);
+            launch_tile<T, EPI, Cfg8P, true>(s, a, tilesbig * 2);
             return launch_reduce<T, EPI>(s, a);
         }
     }
@@ -1302,8 +1123,8 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
             // 16x16x32 -- the schedule alone is worth nothing here (the tile is bound by the CU's staging rate), the MFMA shape is: the
             // chip holds a higher clock on it under sustained load.  force_cfg 256 | 0x4000 = stage ring, | 0x8000 = 32x32x16 form (tests)
             if (!a.a_scale && a.zeros && !(a.force_cfg & 0x4000)) {
-                if (a.force_cfg & 0x8000) hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, Cfg8P32, false>), dim3(tilesbig), dim3(Cfg8P32::THREADS), Cfg8P32::LDS_BYTES, s, a);
-                else hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, Cfg8P, false>), dim3(tilesbig), dim3(Cfg8P::THREADS), Cfg8P::LDS_BYTES, s, a);
+                if (a.force_cfg & 0x8000) launch_tile<T, EPI, Cfg8P32, false>(s, a, tilesbig);
+                else launch_tile<T, EPI, Cfg8P, false>(s, a, tilesbig);
                 return false;
             }
         }
@@ -1319,6 +1140,32 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     // 10.9 + 10.2 for the K-split product whose reduce emits the norm (one-frame ViT 3.69 -> 3.60 ms).
     // (Also measured and NOT kept: a 4-deep ring for one-round 128x128 launches, 19.9 vs 19.4 us on ViT qkv; issuing the LDS-DMA
     //  pieces of the next stage one by one between the MFMAs instead of as a burst ahead of them: 5-25 % slower on every config.)
+    // 256x64 tiles (8 waves stacked along M, the CDNA guide's tile for M = 256 projections) for the short-K, few-column products of a
+    // steady prefill -- q|k|v (N 4608) and o_proj (N 3584) at K = 3584: 72 / 56 tiles x 3-4 K slices instead of 36 / 28 tiles x 7-9, i.e.
+    // half the fp32 slab traffic for twice the re-staged activation bytes.  Measured inside the turn, two alternating rounds
+    // (steady prefill per turn): both products -0.11 / -0.14 ms, q|k|v alone -0.08 / 0.00, with down_proj (K = 18944) as well +0.03 /
+    // +0.11, gate/up +0.44 / +0.49 (one round of 128-wide tiles is what that product wants); a forced 2-way split +1.05.
+    const bool n64 = fc == 0 && a.force_split == 0 && EPI == EPI_NONE && a.M > 32 && a.M <= 256 && a.N <= 4608 && a.N >= 1024 && a.K <= 4096 && a.K >= 1024;
+    // ... and the one-frame SigLIP out_proj (729 x 1152 x 1152, three row tiles: weights stay cached, not nt): 54 tiles x 3 K slices against
+    // 27 tiles x 9, a third of the fp32 slabs the LayerNorm-emitting reduce reads: vision per turn 4.10 -> 4.00 ms in two alternating
+    // rounds; fc2 (K = 4304) measured equal at 4 slices and +0.25 ms at 6, and keeps the 256x128 tile.
+    const bool vit64 = fc == 0 && a.force_split == 0 && EPI == EPI_NONE && a.M > 512 && a.M <= 768 && a.N <= 1280 && a.K <= 1280 && a.norm_out != nullptr;
+    if (vit64) a.force_split = 3;
+    if ((fc == 264 || n64 || vit64) && a.zeros && !a.a_scale) {
+        // K split so that about one round of workgroups exists (force_split overrides); several row tiles (forced only): weights cached, not nt
+        const int tiles = ((a.M + 255) / 256) * ((a.N + 63) / 64), st = (a.K / EPC + Cfg256N64::CH - 1) / Cfg256N64::CH;
+        const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0);
+        int S = a.force_split > 0 ? a.force_split : 256 / tiles;
+        if (S < 1) S = 1;
+        if (S > st / 2) S = st / 2 < 1 ? 1 : st / 2;
+        if (!can_split) S = 1;
+        while (S > 1 && (size_t)S * a.M * a.N > a.ws_elems) --S;
+        a.launch_tiles = tiles;
+        if (S <= 1) { a.nsplit = 1; launch_cfg<T, EPI, Cfg256N64, false>(s, a, 1); return false; }
+        a.nsplit = S;
+        launch_cfg<T, EPI, Cfg256N64, true>(s, a, S);
+        return launch_reduce<T, EPI>(s, a);
+    }
     if (fc == 64 && a.zeros) {
         a.nsplit = 1;
         a.launch_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
@@ -1329,7 +1176,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     // fused into a slab reduce -- the one-frame ViT qkv (K / V^T packing) and fc1 (GELU), the projector products: two K-groups inside the
     // workgroup (Cfg128K2) instead of a K split over workgroups + fp32 slabs + a reduce launch.
     const int stages128 = (a.K / EPC + Cfg128::CH - 1) / Cfg128::CH;
-    const bool kgroups = a.zeros && !(a.force_cfg & 0x2000) && a.force_split == 0 &&
+    const bool kgroups = a.force_split == 0 &&
                          ((fc == 0 && a.M > 256 && tiles128 >= 96 && tiles128 <= 256 && stages128 >= 8 && !a.norm_out && !a.rope) || fc == 129);
     if (kgroups) {
         a.nsplit = 1;
@@ -1339,7 +1186,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         }
         if constexpr (EPI == EPI_NONE) {
             if (a.vp_on && !a.a_scale) {
-                hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_NONE, Cfg128K2, false, T, false, true>), dim3(tiles128), dim3(Cfg128K2::THREADS), Cfg128K2::LDS_BYTES, s, a);
+                launch_tile<T, EPI_NONE, Cfg128K2, false, T, false, true>(s, a, tiles128);
                 return true;
             }
         }
@@ -1351,7 +1198,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     if ((want128 && a.force_split == 0) || fc == 128) {
         a.nsplit = 1;
         a.launch_tiles = tiles128;
-        if (tiles128 > 256 && a.zeros && !(a.force_cfg & 0x2000)) launch_cfg<T, EPI, Cfg128L, false>(s, a, 1);
+        if (tiles128 > 256) launch_cfg<T, EPI, Cfg128L, false>(s, a, 1);
         else launch_cfg<T, EPI, Cfg128, false>(s, a, 1);
         return false;
     }
@@ -1402,7 +1249,7 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
 template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a) {
     a.nt_w = 1; a.tile_base = 0; a.nsplit = 1; a.vp_on = 0; a.bn_fast = 0;
     a.launch_tiles = (a.N + 127) / 128;
-    hipLaunchKernelGGL((gemm_glds_kernel<T, EPI_ARGMAX, CfgSkinny, false, T, true>), dim3(a.launch_tiles), dim3(CfgSkinny::THREADS), CfgSkinny::LDS_BYTES, s, a);
+    launch_tile<T, EPI_ARGMAX, CfgSkinny, false, T, true>(s, a, a.launch_tiles);
     return a.launch_tiles;
 }
 template int launch_gemm_argmax<bf16>(hipStream_t, GemmArgs);
@@ -1420,9 +1267,6 @@ template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a) {
 }
 
 template <typename T, int EPI> static void gemm_attr() {
-    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg128, false>, 2 * Cfg128::STAGE_BYTES, Cfg128::THREADS);
-    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg256, false>, 2 * Cfg256::STAGE_BYTES, Cfg256::THREADS);
-    set_max_lds((const void*)gemm_nt_kernel<T, EPI, Cfg256, true>, 2 * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128, false>, Cfg128::NBUF * Cfg128::STAGE_BYTES, Cfg128::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, false>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256, true>, Cfg256::NBUF * Cfg256::STAGE_BYTES, Cfg256::THREADS);
@@ -1433,6 +1277,10 @@ template <typename T, int EPI> static void gemm_attr() {
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, false>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, CfgSkinny, true>, CfgSkinny::NBUF * CfgSkinny::STAGE_BYTES, CfgSkinny::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg64, false>, Cfg64::NBUF * Cfg64::STAGE_BYTES, Cfg64::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256N64, false>, Cfg256N64::LDS_BYTES, Cfg256N64::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256N64, true>, Cfg256N64::LDS_BYTES, Cfg256N64::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256N64, false, T, true>, Cfg256N64::LDS_BYTES, Cfg256N64::THREADS);
+    set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg256N64, true, T, true>, Cfg256N64::LDS_BYTES, Cfg256N64::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128L, false>, Cfg128L::NBUF * Cfg128L::STAGE_BYTES, Cfg128L::THREADS);
     set_max_lds((const void*)gemm_glds_kernel<T, EPI, Cfg128K2, false>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);
     if constexpr (EPI == EPI_NONE) set_max_lds((const void*)gemm_glds_kernel<T, EPI_NONE, Cfg128K2, false, T, false, true>, Cfg128K2::LDS_BYTES, Cfg128K2::THREADS);

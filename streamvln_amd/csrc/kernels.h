@@ -29,7 +29,7 @@ struct GemmArgs {
     int nsplit, tile_base, launch_tiles;   // filled by the launcher (K splits; first column tile and tile count of this launch)
     int nt_w;                              // filled by the launcher: stage the weight tile with non-temporal loads (weights read once)
     int bn_fast;                           // filled by the launcher: consecutive workgroups walk the COLUMN tiles of one row tile (activations larger than weights)
-    const void* zeros;            // >= 16 B of zeros in device memory (K-tail source of the LDS-DMA path); null -> register-staged kernel
+    const void* zeros;            // >= 16 B of zeros in device memory: the K-tail source of the LDS-DMA staging (required)
     // optional fused RMSNorm of the finished output rows (o_proj -> post_attention_layernorm, down_proj -> next input_layernorm):
     // when the product takes the split-K path with N <= 4096 the slab reduce also writes norm_out = rmsnorm(C) * norm_w and
     // launch_gemm returns true; otherwise norm_out is untouched (false) and the caller runs launch_rmsnorm itself
@@ -55,7 +55,7 @@ struct GemmArgs {
     float* part_val = nullptr; int* part_idx = nullptr;
     const uint8_t* pen_flags = nullptr; const int* pen_rows = nullptr; float pen = 1.0f;
     VitPackArgs vp; int vp_on;    // filled by the launcher: device-side copy of *vitpack for the unsplit kernels that pack in their epilogue
-    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 129 -> 128x128 tiles with two in-workgroup K groups; force_cfg low bits 128 -> 128x128 tiles, | 0x2000 -> register-staged (non-glds) kernel; force_split S -> 256x128 tiles, S splits
+    int force_cfg, force_split;   // tests: 0 = heuristic; force_cfg 129 -> 128x128 tiles with two in-workgroup K groups; force_cfg low bits 128 -> 128x128 tiles, 264 -> 256x64 tiles; force_split S -> 256x128 tiles, S splits
 };
 template <typename T> bool launch_gemm(hipStream_t s, const GemmArgs& a);   // true: a.norm_out was produced
 template <typename T> int launch_gemm_argmax(hipStream_t s, GemmArgs a);    // EPI_ARGMAX form (M <= 32); returns the partials per row

@@ -27,7 +27,10 @@ from test_e2e_gpu import _note, _run
 
 pytestmark = pytest.mark.gpu
 
-MARGIN = 0.05                 # ids are asserted wherever the emulation's top-2 logit margin exceeds this (as for bf16 vs fp32)
+MARGIN = 0.05                 # weight-only mode: ids are asserted wherever the emulation's top-2 logit margin exceeds this (as for bf16 vs fp32)
+# w8a8 modes: the hidden row may sit several per cent from the emulation's (quantiser flips, module docstring), i.e. logits move by several
+# per cent of their size (~ 0.1-0.3 here): ids are asserted only above this margin; a flip below it ends the episode's comparable rows
+MARGIN_W8A8 = 0.5
 # relative L2 bound of a final-norm hidden row, engine vs emulation of the same scheme
 W8_REL = {"tiny": 1.2e-2, "true_dims_4layer": 1.2e-2, "streamvln_qwen2_7b": 3e-2}       # = the bf16 engine's own bounds (weight-only)
 # w8a8: delta ~ 5e-3 (the bf16 engine's own distance from the fp32 oracle) through 4 activation quantisers per layer with steps of
@@ -59,6 +62,7 @@ def _rel(a, b):
 
 
 def _oracle_runs(cfg, sc, modes, seeds, workers=16):
+    """`seeds`: a tuple used for every mode, or {mode: tuple}"""
     """{(mode, seed): [(ids, hidden [n,H], margins, cache_len) per turn]} from the emulating CPU oracle; the dequantised weight copies are
     shared by all modes"""
     from oracle import streamvln_oracle as O
@@ -72,7 +76,7 @@ def _oracle_runs(cfg, sc, modes, seeds, workers=16):
         if mode != "plain":
             emu = O.Fp8Emu(decode=mode in ("decode", "both"), gemm=mode in ("gemm", "both"))
             emu._dq = shared
-        for seed in seeds:
+        for seed in (seeds[mode] if isinstance(seeds, dict) else seeds):
             orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"], fp8=emu)
             log = run_scenario(orc, dict(sc, prompt_seed=seed), preprocess=pre)
             out[(mode, seed)] = [(r["out"].sequences[0].tolist(), r["out"].hidden.numpy().copy(), list(r["out"].margins), r["out"].cache_len)
@@ -90,6 +94,7 @@ def _set_mode(m, mode):
 
 def _compare(m, sc, exp, mode, seeds, bound):
     """engine (bf16 + the e4m3 mode) against the emulation: returns (rows compared, decode rows among them, ids asserted, worst rel)"""
+    margin_min = MARGIN if mode == "decode" else MARGIN_W8A8
     rows = dec_rows = asserted = 0
     worst = 0.0
     for seed in seeds:
@@ -108,7 +113,7 @@ def _compare(m, sc, exp, mode, seeds, bound):
                 assert rel < bound, (mode, seed, t, j, rel, bound)
                 rows += 1
                 dec_rows += j > 0
-                if margins[j] > MARGIN:
+                if margins[j] > margin_min:
                     assert ids[j] == gold[j], (mode, seed, t, j, ids, gold, margins)
                     asserted += 1
             if n < len(gold):
@@ -124,17 +129,19 @@ def test_fp8_modes_vs_emulating_oracle(name):
     three mode combinations against the live emulation.  At least 8 comparable rows per mode, decode rows among them."""
     sc = dict(SCENARIOS[name], eos_mod=0)
     cfg = sc["cfg"]
-    seeds = (7, 11, 13, 17) if name == "tiny_episode" else (7, 11, 13)   # (an episode stops being comparable at its first low-margin id flip)
+    # (an episode stops being comparable at its first low-margin id flip: the w8a8 modes need more prompt seeds for their 8 rows)
     modes = ("decode", "gemm", "both")
-    exp = _oracle_runs(cfg, sc, modes, seeds)
+    few, many = ((7, 11), (7, 11, 13, 17)) if name == "tiny_episode" else ((7, 11), (7, 11, 13, 17, 19))
+    seeds_of = {"decode": few, "gemm": many, "both": many}
+    exp = _oracle_runs(cfg, sc, modes, seeds_of)
     m = StreamVLNForCausalLM(cfg, dtype=torch.bfloat16, max_envs=1, max_frames=1 + sc["num_history"], max_positions=2048)
     m.load_synthetic(SEED)
     m.model.num_history = sc["num_history"]
     for mode in modes:
         bound = W8_REL[cfg.name] if mode == "decode" else W8A8_REL[cfg.name]
-        rows, dec_rows, asserted, worst = _compare(m, sc, exp, mode, seeds, bound)
+        rows, dec_rows, asserted, worst = _compare(m, sc, exp, mode, seeds_of[mode], bound)
         line = (f"{cfg.name} fp8 mode '{mode}' vs the emulating oracle: {rows} comparable hidden rows ({dec_rows} decode rows) all < {bound}, "
-                f"worst rel L2 {worst:.4f}; {asserted} ids with emulation margin > {MARGIN} asserted equal")
+                f"worst rel L2 {worst:.4f}; {asserted} ids with emulation margin > {MARGIN if mode == 'decode' else MARGIN_W8A8} asserted equal")
         print(line)
         _note("fp8_vs_emulation", line)
         _note_json(f"{cfg.name}/{mode}", {"rows": rows, "decode_rows": dec_rows, "ids_asserted": asserted, "hidden_rel_l2_worst": round(worst, 5),

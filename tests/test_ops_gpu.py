@@ -33,7 +33,7 @@ def chk(rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (128 | 0x2000, 0), (0x2000, 2), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (258, 0), (0x10000, 0), (128 | 0x10000, 0), (256 | 0x10000, 0), (32, 0), (32, 4), (64, 0), (129, 0)])   # 0x2000 = register-staged kernel; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 258 = 256x256 tiles, two K slices on the 8-phase kernel; | 0x10000 = column tiles fastest in the workgroup order; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
+@pytest.mark.parametrize("cfgsplit", [(0, 0), (128, 0), (0, 1), (0, 3), (256, 0), (256 | 0x4000, 0), (256 | 0x8000, 0), (258, 0), (0x10000, 0), (128 | 0x10000, 0), (256 | 0x10000, 0), (32, 0), (32, 4), (64, 0), (129, 0), (264, 0), (264, 3)])   # 264 = 256x64 tiles (M <= 256), 8 waves stacked along M; 256 = 256x256 tiles (bf16: the 8-phase schedule; | 0x8000: its 32x32x16 form; | 0x4000: the stage-ring kernel); 258 = 256x256 tiles, two K slices on the 8-phase kernel; | 0x10000 = column tiles fastest in the workgroup order; 32 = 32x128 tiles (M <= 32 only); 64 = 64x64 tiles; 129 = 128x128 tiles, two in-workgroup K groups
 @pytest.mark.parametrize("M,N,K,epi,bias,res", [
     (212, 512, 3584, _lib.EPI_NONE, True, False),        # qkv-like, ragged M
     (300, 384, 1152, _lib.EPI_NONE, True, True),         # out_proj + residual

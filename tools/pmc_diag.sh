@@ -1,5 +1,12 @@
 # Where a GEMM product spends its cycles: memory-path counters of the main gemm_glds launch (one kbench run per counter group; rocprofv3
-# --pmc alone, as the pool requires; the TA / TD counter groups hang the profiler on this pool and are left out).  bash tools/pmc_diag.sh "<M,N,K,epi,force_cfg,force_split>" [...]   -> gpurun_out/pmc_diag.txt
+# --pmc alone, as the pool requires).  Two TA / TD groups of the first version are left out:
+#   "TA_BUSY_avr TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+#   "TD_TD_BUSY_sum TD_TC_STALL_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
+# rocprofv3 refused them when it built the counter configuration -- rocprofiler_create_counter_config: "error code 38: Request exceeds
+# the capabilities of the hardware to collect" -- and aborted the process (signal 6) while the engine was being created; the pass did
+# not hang, it died before any kernel ran (log: profiles/r03_pmc_diag_TA_group_refused.log).  Four TA counters (plus a derived _avr
+# one) in ONE pass are more than the TA block's counter slots on gfx950 take; such a group has to be split into passes of one or two
+# counters.  Not done: the TCP / TCC groups below answered the question, and the refused groups were not run again.  bash tools/pmc_diag.sh "<M,N,K,epi,force_cfg,force_split>" [...]   -> gpurun_out/pmc_diag.txt
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_diag
 rm -rf $OUT && mkdir -p $OUT
