@@ -4,14 +4,15 @@
 // (attn_combine, o GEMV, gate/up GEMV, down GEMV, qkv GEMV).  A decode step is HBM-bound on its weight stream (466 MB per layer at true
 // size); what the launched form loses is the ramp / tail of every short kernel and the latency chain between them, during which HBM idles.
 // Here the stream never stops:
-//   * wave 0 of every workgroup is a LOADER: it moves this CU's share of the four weight matrices, in consumption order, HBM -> LDS by
-//     LDS-DMA (global_load_lds, non-temporal) into a ring of 16 KiB slots, up to D slots in flight behind a counted s_waitcnt vmcnt, and
-//     runs ahead of every dependency as far as the ring has room;
-//   * waves 1-3 are CONSUMERS: fp32 FMA dot products of the weight bytes in the ring against the op's input vector in LDS; a weight row
+//   * waves 0-3 of every workgroup are LOADERS: together they move this CU's share of the four weight matrices, in consumption order,
+//     HBM -> LDS by LDS-DMA (global_load_lds, non-temporal) into a ring of 16 KiB slots (wave l issues every fourth 1 KiB block), up to D
+//     slots in flight behind each wave's counted s_waitcnt vmcnt, and run ahead of every dependency as far as the ring has room.  Four,
+//     because one wave streams only ~9 GB/s whatever its depth and four reach the chip's 6.6 TB/s (tools/micro/stream_layout.hip);
+//   * waves 4-7 are CONSUMERS: fp32 FMA dot products of the weight bytes in the ring against the op's input vector in LDS; a weight row
 //     (or a [gate | up] row pair) belongs to one wave, which carries its accumulator across slots;
 //   * a CU owns outputs [c * N / G, (c + 1) * N / G) of every product, so every product's input is an ALL-GATHER of the previous product's
 //     output over all CUs.  The four edges (attention out, x after o_proj, SwiGLU product, x after down_proj) are data-tagged granules
-//     (CDNA guide, Guideline 16 R2): 8 bytes {tag, payload} written by ONE sc1 store each, swept by the three consumer waves with 16
+//     (CDNA guide, Guideline 16 R2): 8 bytes {tag, payload} written by ONE sc1 store each, swept by the consumer waves with 16
 //     loads in flight per lane until every tag equals this launch's epoch; no flag, no fence.  Measured in this harness
 //     (tools/micro/seam_bench.hip): 2.9-3.1 us for the 14 KB edges, 5.5-5.7 us for the 74 KB one, against 6.4 us for an XCD-hierarchical
 //     grid barrier; the loader's run-ahead hides most of it.
@@ -37,11 +38,14 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int SLOT = 16384, BLK = 1024, BPS = SLOT / BLK;      // ring slot, bytes per LDS-DMA wave instruction, blocks per slot
-constexpr int NCONS = 3;
+// Waves of a workgroup: NLOAD loaders + NCONS consumers.  ONE wave sustains only ~9 GB/s of LDS-DMA (or register) streaming whatever its
+// depth, two 18, four 26 GB/s per CU = 6.6 TB/s chip-wide (tools/micro/stream_layout.hip, profiles/r04_stream_layout_bench.txt): the first
+// version of this kernel, with one loader wave, streamed 10.7 GB/s per CU and took 202 us per layer.
+constexpr int NLOAD = 4, NCONS = 4, NTHREADS = 64 * (NLOAD + NCONS);
 constexpr unsigned SPIN_LIMIT = 400000u;
 
 // LDS sync words (dynamic LDS tail), all monotonic within a launch
-enum { W_READY = 0, W_FREED = 1 /* +w */, W_UNITS = 4, W_CBAR = 5 /* +w */, W_SS = 8 /* +w (float bits) */, W_N = 16 };
+enum { W_READY = 0 /* +loader */, W_FREED = 4 /* +w */, W_UNITS = 8, W_CBAR = 9 /* +w */, W_SS = 13 /* +w (float bits) */, W_N = 20 };
 
 struct Op {            // one product as this CU sees it
     const char* W; size_t ld_bytes;      // weight matrix, row pitch in bytes
@@ -100,7 +104,7 @@ template <typename T> SVLN_DEV int xs_index(int k, int nch) {
 }
 
 template <typename T, int NS>
-__global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
+__global__ __launch_bounds__(NTHREADS) void decode_layer_kernel(DecodeLayerArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.skip && *p.skip) return;
     constexpr int EPC = Elt<T>::PER_CHUNK, PARTS = EPC / 4, VPG = Gran<T>::VPG;
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
     const int total_slots = has_next ? op_qkv.slot0 + op_qkv.nslots : op_dn.slot0 + op_dn.nslots;
     gu32* giveup = (gu32*)p.giveup;
 
-    if (wave == 0) {
-        // ------------------------------------------------------------------------------------------------ loader
+    if (wave < NLOAD) {
+        // ------------------------------------------------------------------------------------------------ loaders (wave l issues blocks l, l + NLOAD, ... of every slot)
         int cnt[D + 1];                       // loads issued per slot, slots sg - D .. sg (ring of the last D + 1)
 #pragma unroll
         for (int k = 0; k <= D; ++k) cnt[k] = 0;
@@ -151,24 +155,24 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
         // (one call per product with a constant index: the Op fields stay in scalar registers instead of a runtime-indexed private array)
         // issue loop: rows -> 1 KiB blocks, the per-lane source pointer advances by 1 KiB per block (one 64-bit add), the slot position is
         // scalar; per SLOT: room check before its first block, counted wait + publish after its last
-        int b = 0;                            // blocks issued into the current slot
+        int b = 0, mine = 0;                  // blocks of the current slot walked so far / issued by THIS wave
         int published = 0;                    // slots announced to the consumers (W_READY)
         char* dst = ring;
         auto slot_begin = [&](int oi) {
             if (sg >= NS && !dead) {          // slot sg reuses the buffer of slot sg - NS, which every consumer must have released
                 unsigned spins = 0;
                 for (;;) {
-                    unsigned f0, f1, f2;      // (three reads in flight, one wait)
-                    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(f0), "=&v"(f1), "=&v"(f2) : "v"(sync0 + 4 * W_FREED) : "memory");
-                    const unsigned fm = min(f0, min(f1, f2));
+                    unsigned f0, f1, f2, f3;  // (four reads in flight, one wait)
+                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(sync0 + 4 * W_FREED) : "memory");
+                    const unsigned fm = min(min(f0, f1), min(f2, f3));
                     if ((int)fm + NS > sg) break;
                     if (spins == 0) {
                         // the ring is full: the consumers are behind (an edge).  Nothing can be issued, so waiting for everything in
                         // flight costs nothing -- and publishes the D slots that would otherwise stay unannounced until the next issue
                         wait_vm<0>();
                         published = sg;
-                        lds_write_u32(sync0 + 4 * W_READY, (unsigned)sg);
+                        lds_write_u32(sync0 + 4 * (W_READY + wave), (unsigned)sg);
 #pragma unroll
                         for (int k = 0; k <= D; ++k) cnt[k] = 0;
                     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
                 wait_vm_le(outstanding);
                 if (sg - D + 1 > published) {         // (never move the published count backwards: a blocked loader may have published further)
                     published = sg - D + 1;
-                    lds_write_u32(sync0 + 4 * W_READY, (unsigned)published);
+                    lds_write_u32(sync0 + 4 * (W_READY + wave), (unsigned)published);
                 }
             }
             ++sg;
@@ -200,31 +204,34 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
             for (int j = 0; j < o.nrows; ++j) {
                 const char* src = o.W + op_row(o, j) * o.ld_bytes + lane * 16;
                 for (int pb = 0; pb < o.bpr; ++pb) {
-                    if (b == 0) slot_begin(oi);
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + b * BLK), 16, 0, 2);      // aux 2 = non-temporal: read once, by this CU
+                    if (b == 0) { slot_begin(oi); mine = 0; }
+                    if ((b & (NLOAD - 1)) == wave) {
+                        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + b * BLK), 16, 0, 2);      // aux 2 = non-temporal: read once, by this CU
+                        ++mine;
+                    }
                     src += BLK;
-                    if (++b == BPS) slot_end(BPS);
+                    if (++b == BPS) slot_end(mine);
                 }
             }
-            if (b) slot_end(b);               // the op's last, partial slot (the next op starts a new slot)
+            if (b) slot_end(mine);            // the op's last, partial slot (the next op starts a new slot)
         };
-        stamp(10);
+        if (wave == 0) stamp(10);
         stream_op(op_o, 0);
-        stamp(11);
+        if (wave == 0) stamp(11);
         stream_op(op_gu, 1);
-        stamp(12);
+        if (wave == 0) stamp(12);
         stream_op(op_dn, 2);
-        stamp(13);
+        if (wave == 0) stamp(13);
         if (has_next) stream_op(op_qkv, 3);
         wait_vm<0>();
-        stamp(14);
-        lds_write_u32(sync0 + 4 * W_READY, (unsigned)total_slots);
+        if (wave == 0) stamp(14);
+        lds_write_u32(sync0 + 4 * (W_READY + wave), (unsigned)total_slots);
         return;
     }
 
     // ---------------------------------------------------------------------------------------------------- consumers
-    const int w = wave - 1;
-    const int ctid = tid - 64;                                 // 0 .. 191
+    const int w = wave - NLOAD;
+    const int ctid = tid - 64 * NLOAD;                         // 0 .. 64 * NCONS - 1
     bool dead = false;
     auto fail = [&](unsigned code) { dead = true; __hip_atomic_store(giveup, code, RLX_AGENT); };
     volatile unsigned* vs = syncw;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) vs[W_CBAR + w] = cb_epoch;
         unsigned spins = 0;
-        while (!dead && (vs[W_CBAR] < cb_epoch || vs[W_CBAR + 1] < cb_epoch || vs[W_CBAR + 2] < cb_epoch)) {
+        while (!dead && (vs[W_CBAR] < cb_epoch || vs[W_CBAR + 1] < cb_epoch || vs[W_CBAR + 2] < cb_epoch || vs[W_CBAR + 3] < cb_epoch)) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) fail(0x200u + cb_epoch);
         }
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
         ss = wave_sum(ss);
         if (lane == 0) vs[W_SS + w] = __float_as_uint(ss);
         cbarrier();
-        const float tot = __uint_as_float(vs[W_SS]) + __uint_as_float(vs[W_SS + 1]) + __uint_as_float(vs[W_SS + 2]);
+        const float tot = __uint_as_float(vs[W_SS]) + __uint_as_float(vs[W_SS + 1]) + __uint_as_float(vs[W_SS + 2]) + __uint_as_float(vs[W_SS + 3]);
         cbarrier();                           // (W_SS is rewritten by the next norm: everyone has read it)
         return rsqrtf(tot / (float)H + p.eps);
     };
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void decode_layer_kernel(DecodeLayerArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // this wave's reads of the earlier slots are done
         if (lane == 0) vs[W_FREED + w] = (unsigned)sg;
         unsigned spins = 0;
-        while (!dead && (int)vs[W_READY] <= sg) {
+        while (!dead && (int)min(min(vs[W_READY], vs[W_READY + 1]), min(vs[W_READY + 2], vs[W_READY + 3])) <= sg) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) fail(0x500u + (unsigned)oi);
         }
@@ -510,12 +517,12 @@ template <typename T> bool decode_layer_supported(const DecodeLayerArgs& a, int 
     return layer_lds_bytes<T>(a) <= (size_t)160 * 1024;
 }
 template <typename T> void launch_decode_layer(hipStream_t s, const DecodeLayerArgs& a, int cus, hipEvent_t start, hipEvent_t stop) {
-    if (start || stop) hipExtLaunchKernelGGL((decode_layer_kernel<T, ring_slots<T>()>), dim3(cus), dim3(256), layer_lds_bytes<T>(a), s, start, stop, 0, a);
-    else hipLaunchKernelGGL((decode_layer_kernel<T, ring_slots<T>()>), dim3(cus), dim3(256), layer_lds_bytes<T>(a), s, a);
+    if (start || stop) hipExtLaunchKernelGGL((decode_layer_kernel<T, ring_slots<T>()>), dim3(cus), dim3(NTHREADS), layer_lds_bytes<T>(a), s, start, stop, 0, a);
+    else hipLaunchKernelGGL((decode_layer_kernel<T, ring_slots<T>()>), dim3(cus), dim3(NTHREADS), layer_lds_bytes<T>(a), s, a);
 }
 void decode_layer_init_attrs() {
-    set_max_lds((const void*)decode_layer_kernel<bf16, ring_slots<bf16>()>, 160 * 1024, 256);
-    set_max_lds((const void*)decode_layer_kernel<float, ring_slots<float>()>, 160 * 1024, 256);
+    set_max_lds((const void*)decode_layer_kernel<bf16, ring_slots<bf16>()>, 160 * 1024, NTHREADS);
+    set_max_lds((const void*)decode_layer_kernel<float, ring_slots<float>()>, 160 * 1024, NTHREADS);
 }
 template bool decode_layer_supported<bf16>(const DecodeLayerArgs&, int);
 template bool decode_layer_supported<float>(const DecodeLayerArgs&, int);
