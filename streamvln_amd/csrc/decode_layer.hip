@@ -3,23 +3,26 @@
 // input_layernorm + q|k|v projection (modeling_qwen2.py:269-299) -- as ONE launch of one workgroup per CU, instead of five launches
 // (attn_combine, o GEMV, gate/up GEMV, down GEMV, qkv GEMV).  A decode step is HBM-bound on its weight stream (466 MB per layer at true
 // size); what the launched form loses is the ramp / tail of every short kernel and the latency chain between them, during which HBM idles.
-// Here the stream never stops:
-//   * waves 0-3 of every workgroup are LOADERS: together they move this CU's share of the four weight matrices, in consumption order,
-//     HBM -> LDS by LDS-DMA (global_load_lds, non-temporal) into a ring of 16 KiB slots (wave l issues every fourth 1 KiB block), up to D
-//     slots in flight behind each wave's counted s_waitcnt vmcnt, and run ahead of every dependency as far as the ring has room.  Four,
-//     because one wave streams only ~9 GB/s whatever its depth and four reach the chip's 6.6 TB/s (tools/micro/stream_layout.hip);
-//   * waves 4-7 are CONSUMERS: fp32 FMA dot products of the weight bytes in the ring against the op's input vector in LDS; a weight row
-//     (or a [gate | up] row pair) belongs to one wave, which carries its accumulator across slots;
-//   * a CU owns outputs [c * N / G, (c + 1) * N / G) of every product, so every product's input is an ALL-GATHER of the previous product's
-//     output over all CUs.  The four edges (attention out, x after o_proj, SwiGLU product, x after down_proj) are data-tagged granules
-//     (CDNA guide, Guideline 16 R2): 8 bytes {tag, payload} written by ONE sc1 store each, swept by the consumer waves with 16
-//     loads in flight per lane until every tag equals this launch's epoch; no flag, no fence.  Measured in this harness
-//     (tools/micro/seam_bench.hip): 2.9-3.1 us for the 14 KB edges, 5.5-5.7 us for the 74 KB one, against 6.4 us for an XCD-hierarchical
-//     grid barrier; the loader's run-ahead hides most of it.
+//
+// Structure (third form; the two LDS-ring forms before it are described in DESIGN.md 4.1).  What sets the streaming rate of a CU is
+// the number of BYTES IN FLIGHT: chip-wide streaming sees ~5 us of loaded HBM latency, so 6.3 TB/s needs ~128 KB in flight per CU
+// (tools/micro/stream_layout.hip: 9 / 18 / 26 GB/s per CU at 40 / 90 / 110 KB in flight, LDS-DMA and register loads alike).  An LDS ring
+// next to the 58 KB of activation vectors tops out at 48-64 KB (measured: 10.7 GB/s per CU, 202 us per layer).  Registers do not:
+//   * all 8 waves of the workgroup stream: each keeps PF = 16 one-KiB blocks (16 B per lane, non-temporal) of ITS share of the weights in
+//     flight in registers (8 x 16 KB = 128 KB per CU), computes block i while block i + 16 loads, and -- because the weights do not depend
+//     on the activations -- its prefetch runs across the product boundaries: while the workgroup waits at an edge, the first 16 blocks of
+//     the next product are already on their way;
+//   * a CU owns outputs [c * N / G, (c + 1) * N / G) of every product.  Rows of K <= 15 KiB go to waves whole (round-robin); longer rows
+//     (down_proj) are dealt to the waves block by block, the per-(row, wave) partial sums meet in LDS and are added in a fixed order;
+//   * every product's input is an ALL-GATHER of the previous product's output over all CUs: four edges (attention out, x after o_proj,
+//     SwiGLU product, x after down_proj) as data-tagged granules (CDNA guide, Guideline 16 R2): 8 bytes {tag, payload} written by ONE sc1
+//     store each, swept by all waves with several loads in flight per lane until every tag equals this launch's epoch; no flag, no fence,
+//     no grid barrier.  Measured in this harness (tools/micro/seam_bench.hip): 2.9-3.1 us for the 14 KB edges, 5.5-5.7 us for the 74 KB
+//     one, against 6.4 us for an XCD-hierarchical grid barrier.
 // The attention itself (RoPE, KV append, per-page partials) stays the launch it was (attn_decode_kernel): its partials reach this kernel
 // across a kernel boundary, which needs no hand-off.
 // Arithmetic per output = the launched kernels' (gemv.hip): fp32 FMA over K, RMSNorm folded as rstd * (W . (g * x)), one rounding to T
-// per stored value; the summation ORDER over K differs (lane-strided blocks here), so results agree to fp32 rounding, not bit for bit.
+// per stored value; the summation ORDER over K differs, so results agree to fp32 rounding, not bit for bit.
 // Every spin is bounded: on a timeout a give-up code is stored, every later wait falls through and the grid drains; the host reads
 // the word after the turn's synchronisation (svln_generate fails with it).
 #include <hip/hip_ext.h>
@@ -31,27 +34,25 @@ namespace svln {
 
 namespace {
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr int SLOT = 16384, BLK = 1024, BPS = SLOT / BLK;      // ring slot, bytes per LDS-DMA wave instruction, blocks per slot
-// Waves of a workgroup: NLOAD loaders + NCONS consumers.  ONE wave sustains only ~9 GB/s of LDS-DMA (or register) streaming whatever its
-// depth, two 18, four 26 GB/s per CU = 6.6 TB/s chip-wide (tools/micro/stream_layout.hip, profiles/r04_stream_layout_bench.txt): the first
-// version of this kernel, with one loader wave, streamed 10.7 GB/s per CU and took 202 us per layer.
-constexpr int NLOAD = 4, NCONS = 4, NTHREADS = 64 * (NLOAD + NCONS);
-constexpr unsigned SPIN_LIMIT = 400000u;
-
-// LDS sync words (dynamic LDS tail), all monotonic within a launch
-enum { W_READY = 0 /* +loader */, W_FREED = 4 /* +w */, W_UNITS = 8, W_CBAR = 9 /* +w */, W_SS = 13 /* +w (float bits) */, W_N = 20 };
+constexpr int BLK = 1024;                       // bytes one wave instruction moves (64 lanes x 16 B)
+constexpr int NW = 8, NTHREADS = 64 * NW;       // waves per workgroup: all of them stream and compute
+constexpr int PF = 16;                          // blocks in flight per wave (16 KB: 128 KB per CU; 24 measured slower -- 230 VGPRs -- and 32 no longer unrolls into registers)
+constexpr int ROWMODE_MAX_BPR = 15;             // rows of at most this many blocks go to one wave whole
+constexpr unsigned SPIN_LIMIT = 50000u;
+constexpr size_t LDS_FLOOR = 100 * 1024;        // dynamic LDS requested at least: two workgroups never share a CU
 
 struct Op {            // one product as this CU sees it
     const char* W; size_t ld_bytes;      // weight matrix, row pitch in bytes
-    int rb, bpr;                         // row bytes streamed (K * sizeof(T)), 1 KiB blocks per row
+    int bpr;                             // 1 KiB blocks per row
     int nrows, pair, first;              // stream rows; pair: rows come as (gate j, up j) of the [gate 32 | up 32] packing; first output index
-    int nblk, slot0, nslots;
+    int nblk;                            // blocks of this CU's share
+    int ch;                              // blocks dealt to a wave at a time: bpr (whole rows) or 1
+    int bm;                              // block mode: rows longer than ROWMODE_MAX_BPR blocks, dealt block by block (ch = 1)
 };
 
 SVLN_DEV size_t op_row(const Op& o, int j) {                   // matrix row of stream row j
@@ -59,30 +60,55 @@ SVLN_DEV size_t op_row(const Op& o, int j) {                   // matrix row of 
     const int out = o.first + (j >> 1);
     return (size_t)(out >> 5) * 64 + (out & 31) + (j & 1) * 32;
 }
-
-// LDS words through inline asm: hipcc orders every LDS access it can see behind ALL outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0)),
-// which would drain the loader's ring at every poll (gemm.hip has the same note)
-SVLN_DEV unsigned lds_read_u32(unsigned addr) {
-    unsigned v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+// slots of wave w in op o (chunks of o.ch blocks dealt round-robin), rounded up to whole groups of PF
+SVLN_DEV int op_slots(const Op& o, int w) {
+    const int nchunk = (o.nblk + o.ch - 1) / o.ch;
+    const int mine = nchunk > w ? (nchunk - w + NW - 1) / NW : 0;
+    const int ns = (mine * o.ch + PF - 1) / PF * PF;
+    return ns < PF ? PF : ns;            // at least one group, even without work: the last group of an op is where the next op's first PF slots are loaded
 }
-SVLN_DEV void lds_write_u32(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory"); }
-SVLN_DEV void lds_add_u32(unsigned addr, unsigned v) { asm volatile("ds_add_u32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory"); }
-
-template <int N> SVLN_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-SVLN_DEV void wait_vm_le(int n) {        // at most n (<= 48) of this wave's vector-memory operations still outstanding
-    switch (n) {
-#define SVLN_CASE(k) case k: wait_vm<k>(); break;
-        SVLN_CASE(0) SVLN_CASE(1) SVLN_CASE(2) SVLN_CASE(3) SVLN_CASE(4) SVLN_CASE(5) SVLN_CASE(6) SVLN_CASE(7) SVLN_CASE(8) SVLN_CASE(9)
-        SVLN_CASE(10) SVLN_CASE(11) SVLN_CASE(12) SVLN_CASE(13) SVLN_CASE(14) SVLN_CASE(15) SVLN_CASE(16) SVLN_CASE(17) SVLN_CASE(18) SVLN_CASE(19)
-        SVLN_CASE(20) SVLN_CASE(21) SVLN_CASE(22) SVLN_CASE(23) SVLN_CASE(24) SVLN_CASE(25) SVLN_CASE(26) SVLN_CASE(27) SVLN_CASE(28) SVLN_CASE(29)
-        SVLN_CASE(30) SVLN_CASE(31) SVLN_CASE(32) SVLN_CASE(33) SVLN_CASE(34) SVLN_CASE(35) SVLN_CASE(36) SVLN_CASE(37) SVLN_CASE(38) SVLN_CASE(39)
-        SVLN_CASE(40) SVLN_CASE(41) SVLN_CASE(42) SVLN_CASE(43) SVLN_CASE(44) SVLN_CASE(45) SVLN_CASE(46) SVLN_CASE(47) SVLN_CASE(48)
-#undef SVLN_CASE
-        default: wait_vm<0>(); break;
+// Walking the slots of one wave through one op.  Row mode (o.ch == o.bpr): a chunk is one stream row, rows w, w + NW, ...; block mode
+// (o.ch == 1, rows longer than ROWMODE_MAX_BPR blocks, stored back to back): blocks w, w + NW, ... of the CU's contiguous share.
+// LoadCur yields the source address of every slot (a padding slot re-reads the op's first block); CompCur says which (row, block) a
+// slot is and when a row's partial sum is complete.
+struct LoadCur {
+    const char* ptr; int kc, row, gb;
+    SVLN_DEV const char* row_ptr(const Op& o, int r, int lane) const { return o.W + op_row(o, r < o.nrows ? r : 0) * o.ld_bytes + lane * 16; }
+    SVLN_DEV void start(const Op& o, int w, int lane) {
+        kc = 0; row = w; gb = w;
+        ptr = o.bm ? (w < o.nblk ? o.W + (size_t)o.first * o.ld_bytes + (size_t)w * BLK + lane * 16 : o.W + lane * 16) : row_ptr(o, w, lane);
     }
-}
+    SVLN_DEV void next(const Op& o, int lane) {
+        if (o.bm) {
+            gb += NW;
+            ptr = gb < o.nblk ? ptr + (size_t)NW * BLK : o.W + (size_t)o.first * o.ld_bytes + lane * 16;
+        } else if (++kc == o.ch) {
+            kc = 0; row += NW;
+            ptr = row_ptr(o, row, lane);
+        } else {
+            ptr += BLK;
+        }
+    }
+};
+struct CompCur {
+    int kc, row, pb, gb;
+    SVLN_DEV void start(const Op& o, int w) {
+        kc = 0; gb = w;
+        if (o.bm) { row = w / o.bpr; pb = w - row * o.bpr; } else { row = w; pb = 0; }
+    }
+    SVLN_DEV bool valid(const Op& o) const { return o.bm ? gb < o.nblk : row < o.nrows; }
+    // returns true when the slot just consumed was the last one of its row FOR THIS WAVE (its partial sum is complete)
+    SVLN_DEV bool next(const Op& o) {
+        if (o.bm) {
+            gb += NW; pb += NW;
+            if (pb >= o.bpr) { pb -= o.bpr; ++row; return true; }
+            return false;
+        }
+        if (++kc == o.ch) { kc = 0; row += NW; pb = 0; return true; }
+        ++pb;
+        return false;
+    }
+};
 
 template <typename T> struct Gran;       // payload of one 8-byte granule: two bf16 values, or one fp32 value
 template <> struct Gran<bf16> {
@@ -103,158 +129,202 @@ template <typename T> SVLN_DEV int xs_index(int k, int nch) {
     return (e >> 2) * nch * 4 + ci * 4 + (e & 3);
 }
 
-template <typename T, int NS>
+// The block stream is plain non-temporal loads in STRAIGHT-LINE code: every slot issues exactly one load (an invalid padding slot re-reads
+// a valid block and is not computed) and the source pointer is chosen by selects, not branches, so that hipcc's waitcnt insertion can
+// count -- loads of one wave return in order, and when slot k is consumed PF - 1 younger loads may stay outstanding.  (Inline-asm loads
+// into a register array are NOT safe here: the compiler does not know the destination is still being written and moved / reused those
+// registers -- a first version faulted with a memory aperture violation.)
+SVLN_DEV u32x4_t load_block(const char* p) { return __builtin_nontemporal_load((const u32x4_t*)p); }
+
+template <typename T>
 __global__ __launch_bounds__(NTHREADS) void decode_layer_kernel(DecodeLayerArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.skip && *p.skip) return;
     constexpr int EPC = Elt<T>::PER_CHUNK, PARTS = EPC / 4, VPG = Gran<T>::VPG;
-    constexpr int D = NS >= 5 ? 3 : (NS >= 4 ? 2 : 1);           // slots in flight behind the loader (the rest of the ring: published / being read)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, c = blockIdx.x;
     const int H = p.H, I = p.I, qd = p.qd;
     const int kx = H > qd ? H : qd;
-    char* ring = smem;
-    float* xs = (float*)(ring + (size_t)NS * SLOT);
-    T* xres = (T*)(xs + kx);
-    T* hvec = xres + H;
-    float* outbuf = (float*)(hvec + I);
-    unsigned* syncw = (unsigned*)(outbuf + 128);
-    const unsigned sync0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)syncw;
-    if (tid < W_N) syncw[tid] = 0u;
-    // this launch's epoch: tags of its four edges are seq * 4 + 1 .. + 4 (never 0; unique over all launches, so granules left by earlier
-    // launches -- or zeroed memory -- never match)
-    const unsigned seq = *p.seq;
-    __syncthreads();
-
-    // optional phase stamps (100 MHz wall clock) of this workgroup: [0..9] consumer wave 0, [10..14] the loader (tools / DESIGN.md only)
-    auto stamp = [&](int k) { if (p.dbg && lane == 0) p.dbg[(size_t)c * 16 + k] = wall_clock64(); };
     const bool has_next = p.next_qkv_w != nullptr;
     const int perA = qd / G, perH = H / G, perI = I / G, perQ = has_next ? p.qkv_dim / G : 0;
-    // (four separate objects, never indexed at run time: an array of them lands in scratch memory, and a scratch load in the loader's
-    //  loop makes hipcc wait for vmcnt(0) -- the whole DMA ring -- before every slot)
-    auto mk = [&](const void* W, int K, int nrows, int pair, int first, int slot0) {
+    const int nr_max = max(max(2 * perI, perH), perQ);
+    float* xs = (float*)smem;                        // fp32 planes of the current product's input (g * x folded in)
+    T* xres = (T*)(xs + kx);                         // residual row
+    T* hvec = xres + H;                              // SwiGLU product (down_proj's input)
+    float* part = (float*)(hvec + I);                // [row][wave] partial dot products of the current product
+    float* outbuf = part + (size_t)nr_max * NW;      // this CU's finished outputs of the current product
+    float* ssw = outbuf + 128;                       // per-wave partial sums of squares (RMSNorm)
+    const unsigned seq = *p.seq;                     // this launch's epoch: the tags of its four edges are seq * 4 + 1 .. + 4 (never 0; unique
+                                                     // over all launches, so granules of earlier launches -- or zeroed memory -- never match)
+    gu32* giveup = (gu32*)p.giveup;
+    bool dead = false;
+    auto stamp = [&](int k) { if (p.dbg && tid == 0) p.dbg[(size_t)c * 16 + k] = wall_clock64(); };
+
+    // (separate objects, never indexed at run time: an array of them would live in scratch memory)
+    auto mk = [&](const void* W, int K, int nrows, int pair, int first) {
         Op o;
-        o.W = (const char*)W; o.ld_bytes = (size_t)K * sizeof(T); o.rb = K * (int)sizeof(T); o.bpr = o.rb / BLK;
-        o.nrows = nrows; o.pair = pair; o.first = first; o.nblk = nrows * o.bpr; o.slot0 = slot0; o.nslots = (o.nblk + BPS - 1) / BPS;
+        o.W = (const char*)W; o.ld_bytes = (size_t)K * sizeof(T); o.bpr = K * (int)sizeof(T) / BLK;
+        o.nrows = nrows; o.pair = pair; o.first = first; o.nblk = nrows * o.bpr; o.bm = o.bpr > ROWMODE_MAX_BPR ? 1 : 0; o.ch = o.bm ? 1 : o.bpr;
         return o;
     };
-    const Op op_o = mk(p.o_w, qd, perH, 0, c * perH, 0);
-    const Op op_gu = mk(p.gu_w, H, 2 * perI, 1, c * perI, op_o.nslots);
-    const Op op_dn = mk(p.down_w, I, perH, 0, c * perH, op_gu.slot0 + op_gu.nslots);
-    const Op op_qkv = mk(p.next_qkv_w, H, perQ, 0, c * perQ, op_dn.slot0 + op_dn.nslots);
-    const int total_slots = has_next ? op_qkv.slot0 + op_qkv.nslots : op_dn.slot0 + op_dn.nslots;
-    gu32* giveup = (gu32*)p.giveup;
+    const Op op_o = mk(p.o_w, qd, perH, 0, c * perH);
+    const Op op_gu = mk(p.gu_w, H, 2 * perI, 1, c * perI);
+    const Op op_dn = mk(p.down_w, I, perH, 0, c * perH);
+    const Op op_qkv = mk(p.next_qkv_w, H, perQ, 0, c * perQ);
 
-    if (wave < NLOAD) {
-        // ------------------------------------------------------------------------------------------------ loaders (wave l issues blocks l, l + NLOAD, ... of every slot)
-        int cnt[D + 1];                       // loads issued per slot, slots sg - D .. sg (ring of the last D + 1)
+    u32x4_t buf[PF];                                 // this wave's blocks in flight
+    // the first PF slots of an op into buf (before the op's input exists: the weights do not depend on it)
+    auto prefetch = [&](const Op& o) {
+        LoadCur lc; lc.start(o, wave, lane);
 #pragma unroll
-        for (int k = 0; k <= D; ++k) cnt[k] = 0;
-        int sg = 0, outstanding = 0;
-        bool dead = false;
-        // (one call per product with a constant index: the Op fields stay in scalar registers instead of a runtime-indexed private array)
-        // issue loop: rows -> 1 KiB blocks, the per-lane source pointer advances by 1 KiB per block (one 64-bit add), the slot position is
-        // scalar; per SLOT: room check before its first block, counted wait + publish after its last
-        int b = 0, mine = 0;                  // blocks of the current slot walked so far / issued by THIS wave
-        int published = 0;                    // slots announced to the consumers (W_READY)
-        char* dst = ring;
-        auto slot_begin = [&](int oi) {
-            if (sg >= NS && !dead) {          // slot sg reuses the buffer of slot sg - NS, which every consumer must have released
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned f0, f1, f2, f3;  // (four reads in flight, one wait)
-                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(sync0 + 4 * W_FREED) : "memory");
-                    const unsigned fm = min(min(f0, f1), min(f2, f3));
-                    if ((int)fm + NS > sg) break;
-                    if (spins == 0) {
-                        // the ring is full: the consumers are behind (an edge).  Nothing can be issued, so waiting for everything in
-                        // flight costs nothing -- and publishes the D slots that would otherwise stay unannounced until the next issue
-                        wait_vm<0>();
-                        published = sg;
-                        lds_write_u32(sync0 + 4 * (W_READY + wave), (unsigned)sg);
-#pragma unroll
-                        for (int k = 0; k <= D; ++k) cnt[k] = 0;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > SPIN_LIMIT) { dead = true; __hip_atomic_store(giveup, 0x100u + (unsigned)oi, RLX_AGENT); break; }
-                }
-            }
-            dst = ring + (size_t)(sg % NS) * SLOT;
-        };
-        auto slot_end = [&](int nb) {
-            // slot sg - D has landed once at most the loads of slots sg - D + 1 .. sg are outstanding
-#pragma unroll
-            for (int k = 0; k < D; ++k) cnt[k] = cnt[k + 1];
-            cnt[D] = nb;
-            outstanding = 0;
-#pragma unroll
-            for (int k = 1; k <= D; ++k) outstanding += cnt[k];
-            if (sg >= D) {
-                wait_vm_le(outstanding);
-                if (sg - D + 1 > published) {         // (never move the published count backwards: a blocked loader may have published further)
-                    published = sg - D + 1;
-                    lds_write_u32(sync0 + 4 * (W_READY + wave), (unsigned)published);
-                }
-            }
-            ++sg;
-            b = 0;
-        };
-        auto stream_op = [&](const Op& o, int oi) {
-            for (int j = 0; j < o.nrows; ++j) {
-                const char* src = o.W + op_row(o, j) * o.ld_bytes + lane * 16;
-                for (int pb = 0; pb < o.bpr; ++pb) {
-                    if (b == 0) { slot_begin(oi); mine = 0; }
-                    if ((b & (NLOAD - 1)) == wave) {
-                        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + b * BLK), 16, 0, 2);      // aux 2 = non-temporal: read once, by this CU
-                        ++mine;
-                    }
-                    src += BLK;
-                    if (++b == BPS) slot_end(mine);
-                }
-            }
-            if (b) slot_end(mine);            // the op's last, partial slot (the next op starts a new slot)
-        };
-        if (wave == 0) stamp(10);
-        stream_op(op_o, 0);
-        if (wave == 0) stamp(11);
-        stream_op(op_gu, 1);
-        if (wave == 0) stamp(12);
-        stream_op(op_dn, 2);
-        if (wave == 0) stamp(13);
-        if (has_next) stream_op(op_qkv, 3);
-        wait_vm<0>();
-        if (wave == 0) stamp(14);
-        lds_write_u32(sync0 + 4 * (W_READY + wave), (unsigned)total_slots);
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- consumers
-    const int w = wave - NLOAD;
-    const int ctid = tid - 64 * NLOAD;                         // 0 .. 64 * NCONS - 1
-    bool dead = false;
-    auto fail = [&](unsigned code) { dead = true; __hip_atomic_store(giveup, code, RLX_AGENT); };
-    volatile unsigned* vs = syncw;
-    // consumer-only barrier (the loader never joins an s_barrier after the start): wave w stores its epoch, all wait for the three
-    unsigned cb_epoch = 0;
-    auto cbarrier = [&]() {
-        ++cb_epoch;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) vs[W_CBAR + w] = cb_epoch;
-        unsigned spins = 0;
-        while (!dead && (vs[W_CBAR] < cb_epoch || vs[W_CBAR + 1] < cb_epoch || vs[W_CBAR + 2] < cb_epoch || vs[W_CBAR + 3] < cb_epoch)) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) fail(0x200u + cb_epoch);
+        for (int j = 0; j < PF; ++j) {
+            buf[j] = load_block(lc.ptr);
+            lc.next(o, lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // One product: this wave walks its slots in groups of PF; slot k is computed from buf[k % PF], which is then refilled with slot k + PF --
+    // of this op, or, in the last group, of the NEXT op (its first PF slots: what `prefetch` would load).  xt: the input vector is T values
+    // in `hvec` (down_proj) instead of fp32 planes in `xs`.  A row's partial sum (this wave's blocks of it) goes to part[row][wave].
+    auto product = [&](const Op& o, const Op& rf, bool xt) {      // rf: the op whose first PF slots refill the last group (the next op; o itself after the last)
+        const int ns = op_slots(o, wave), nch = o.bpr * 64;
+        CompCur cc; cc.start(o, wave);
+        LoadCur lc; lc.start(o, wave, lane);
+        for (int j = 0; j < PF; ++j) lc.next(o, lane);             // the load cursor runs PF slots ahead
+        const float* xq0 = xs + lane * 4;                          // this lane's 16 bytes of plane 0 / plane 1 in block 0
+        const float* xq1 = xs + (size_t)nch * 4 + lane * 4;
+        const T* xh = hvec + (size_t)lane * EPC;
+        float acc = 0.0f;
+        auto slot = [&](int j, const char* refill) {
+            if (cc.valid(o)) {
+                float wf[EPC], xf[EPC];
+                chunk_to_f32<T>(make_uint4(buf[j].x, buf[j].y, buf[j].z, buf[j].w), wf);
+                if (xt) {
+                    chunk_to_f32<T>(*(const uint4*)(xh + (size_t)cc.pb * 64 * EPC), xf);
+                } else {
+                    const float4 v0 = *(const float4*)(xq0 + (size_t)cc.pb * 256);
+                    xf[0] = v0.x; xf[1] = v0.y; xf[2] = v0.z; xf[3] = v0.w;
+                    if (PARTS > 1) {
+                        const float4 v1 = *(const float4*)(xq1 + (size_t)cc.pb * 256);
+                        xf[4 % EPC] = v1.x; xf[5 % EPC] = v1.y; xf[6 % EPC] = v1.z; xf[7 % EPC] = v1.w;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc = fmaf(wf[e], xf[e], acc);
+                const int r = cc.row;
+                if (cc.next(o)) {                                   // this wave's last block of row r
+                    const float t = wave_sum(acc);
+                    if (lane == 0) part[r * NW + wave] = t;
+                    acc = 0.0f;
+                }
+            } else {
+                cc.next(o);
+            }
+            buf[j] = load_block(refill);
+        };
+        int k0 = 0;
+        for (; k0 + PF < ns; k0 += PF) {                            // groups refilled from this op
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const char* src = lc.ptr;
+                lc.next(o, lane);
+                slot(j, src);
+            }
+        }
+        LoadCur nc; nc.start(rf, wave, lane);                       // the last group: refilled with the next op's first PF slots
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const char* src = nc.ptr;
+            nc.next(rf, lane);
+            slot(j, src);
+        }
+        // (every row's partial has been written: in block mode a wave's last block of a row is always followed by a slot in a later row --
+        //  valid or not -- because the share is a whole number of rows)
+    };
+    // sum of the NW partials of stream row r, in wave order
+    auto row_sum = [&](int r) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += part[r * NW + q];
+        return t;
+    };
+    auto zero_part = [&](int rows) { for (int k = tid; k < rows * NW; k += NTHREADS) part[k] = 0.0f; };
+    // publish this CU's `per` values of outbuf as granules of edge e (wave 0)
+    auto publish = [&](int e, int per) {
+        if (wave != 0) return;
+        const int gpc = per / VPG;
+        const unsigned tag = seq * 4u + (unsigned)e + 1u;
+        for (int gi = lane; gi < gpc; gi += 64) {
+            float v[2] = {outbuf[gi * VPG], VPG > 1 ? outbuf[gi * VPG + 1] : 0.0f};
+            __hip_atomic_store((gu64*)p.gran[e] + (size_t)c * gpc + gi, ((unsigned long long)tag << 32) | Gran<T>::pack(v), RLX_AGENT);
+        }
+    };
+    // gather edge e (n values from all CUs): every wave sweeps an eighth of the granules, 8 loads in flight per lane, re-reading a batch
+    // until every tag matches; sink(k, value) stores value k of the vector
+    auto gather = [&](int e, int n, auto&& sink) {
+        const unsigned tag = seq * 4u + (unsigned)e + 1u;
+        const int ng = n / VPG, share = (ng + NW - 1) / NW, first = wave * share, count = min(share, ng - first);
+        const unsigned long long* g = p.gran[e];
+        for (int b0 = 0; b0 < count; b0 += 64 * 8) {
+            unsigned spins = 0;
+            for (;;) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int k = b0 + j * 64 + lane;
+                    k = first + (k < count ? k : count - 1);
+                    const unsigned long long* q = g + k;
+                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[j]) : "v"(q) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ok &= (unsigned)(v[j] >> 32) == tag;
+                if (__all(ok) || dead) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = b0 + j * 64 + lane;
+                        if (k < count) {
+                            float f[2];
+                            Gran<T>::unpack((unsigned)v[j], f);
+#pragma unroll
+                            for (int q = 0; q < VPG; ++q) sink((first + k) * VPG + q, f[q]);
+                        }
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(giveup, RLX_AGENT)) { dead = true; __hip_atomic_store(giveup, 0x400u + (unsigned)e, RLX_AGENT); }
+            }
+        }
+    };
+    // gather an H-vector and fold the following RMSNorm: xs = g * x (fp32 planes), optional xres = x; returns rsqrt(mean x^2 + eps)
+    auto gather_norm = [&](int e, const T* gw, bool keep_res, int next_rows) {
+        float ss = 0.0f;
+        const int nch = H / EPC;
+        gather(e, H, [&](int k, float v) {
+            ss = fmaf(v, v, ss);
+            if (keep_res) xres[k] = from_f32<T>(v);
+            xs[xs_index<T>(k, nch)] = v * to_f32(gw[k]);
+        });
+        ss = wave_sum(ss);
+        if (lane == 0) ssw[wave] = ss;
+        zero_part(next_rows);
+        __syncthreads();
+        float tot = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) tot += ssw[q];
+        return rsqrtf(tot / (float)H + p.eps);
     };
 
-    // (0) residual stream of this layer's input, and this CU's slice of the merged attention output
-    for (int ci = ctid; ci < H / EPC; ci += 64 * NCONS) *(uint4*)(xres + (size_t)ci * EPC) = *(const uint4*)((const T*)p.x + (size_t)ci * EPC);
-    if (w == 0) {
+    stamp(9);
+    // (0) residual row of this layer's input; this CU's slice of the merged attention output; o_proj's first blocks on their way.  Loads of a
+    // wave return in order: the small loads go FIRST (behind 16-32 KB of weight blocks the merge's two dependent load rounds took ~12 us),
+    // so the merging wave starts its share of the weight stream only after the merge.
+    for (int ci = tid; ci < H / EPC; ci += NTHREADS) *(uint4*)(xres + (size_t)ci * EPC) = *(const uint4*)((const T*)p.x + (size_t)ci * EPC);
+    if (wave != 1 % NW) prefetch(op_o);
+    if (wave == 1 % NW) {
         // merge of the split-KV partials for this CU's perA output elements (attn_combine_kernel's arithmetic; the sum over the splits is a
-        // wave reduction here): lane z owns split z.  The elements span at most two q heads (perA <= 64 < 128): split weights exp2(m_z - max m)
-        // and the normaliser once per head, then the elements in batches of 16 independent loads per lane.
+        // wave reduction here): lane z owns split z.  The elements span at most two q heads (perA <= 64 < 128).  (Wave 1: wave 0 publishes.)
         const int kv_len = *p.dyn_kv_len, tiles = (kv_len + 63) >> 6;
         const int nsplit = min(min(p.nsplit, 64), (tiles + p.tiles_per_split - 1) / p.tiles_per_split);
         const size_t split_stride = (size_t)p.n_kv * 32 * (128 + ATTN_PART_PAD);
@@ -283,224 +353,78 @@ __global__ __launch_bounds__(NTHREADS) void decode_layer_kernel(DecodeLayerArgs 
                 if (lane == 0 && j0 + j < perA) outbuf[j0 + j] = to_f32(from_f32<T>(sum * (hq == hqA ? invA : invB)));
             }
         }
+        prefetch(op_o);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-
-    unsigned units_target = 0;                 // units finalised by this CU's consumers so far (W_UNITS counts them)
-    // publish this CU's `per` values of outbuf as granules of edge e (consumer wave 0, after all `per` units are in outbuf)
-    auto publish = [&](int e, int per, bool wait_units) {
-        if (w != 0) return;
-        if (wait_units) {
-            unsigned spins = 0;
-            while (!dead && vs[W_UNITS] < units_target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > SPIN_LIMIT) fail(0x300u + (unsigned)e);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        const int gpc = per / VPG;
-        const unsigned tag = seq * 4u + (unsigned)e + 1u;
-        for (int gi = lane; gi < gpc; gi += 64) {
-            float v[2] = {outbuf[gi * VPG], VPG > 1 ? outbuf[gi * VPG + 1] : 0.0f};
-            __hip_atomic_store((gu64*)p.gran[e] + (size_t)c * gpc + gi, ((unsigned long long)tag << 32) | Gran<T>::pack(v), RLX_AGENT);
-        }
-    };
-    // gather edge e (n values from all CUs): the three consumer waves sweep a third of the granules each, 16 loads in flight per lane,
-    // re-reading a batch until every tag matches; sink(k, value) stores value k of the vector
-    auto gather = [&](int e, int n, auto&& sink) {
-        const unsigned tag = seq * 4u + (unsigned)e + 1u;
-        const int ng = n / VPG, third = (ng + NCONS - 1) / NCONS, first = w * third, count = min(third, ng - first);
-        const unsigned long long* g = p.gran[e];
-        for (int b0 = 0; b0 < count; b0 += 64 * 16) {
-            unsigned spins = 0;
-            for (;;) {
-                unsigned long long v[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    int k = b0 + j * 64 + lane;
-                    k = first + (k < count ? k : count - 1);
-                    const unsigned long long* q = g + k;
-                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[j]) : "v"(q) : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                             "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-                bool ok = true;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) ok &= (unsigned)(v[j] >> 32) == tag;
-                if (__all(ok) || dead) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int k = b0 + j * 64 + lane;
-                        if (k < count) {
-                            float f[2];
-                            Gran<T>::unpack((unsigned)v[j], f);
-#pragma unroll
-                            for (int q = 0; q < VPG; ++q) sink((first + k) * VPG + q, f[q]);
-                        }
-                    }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > SPIN_LIMIT / 8) fail(0x400u + (unsigned)e);
-            }
-        }
-    };
-    // gather an H-vector and fold the following RMSNorm: xs = g * x (fp32 planes), optional xres = x; returns rsqrt(mean x^2 + eps)
-    auto gather_norm = [&](int e, const T* gw, bool keep_res) {
-        float ss = 0.0f;
-        const int nch = H / EPC;
-        gather(e, H, [&](int k, float v) {
-            ss = fmaf(v, v, ss);
-            if (keep_res) xres[k] = from_f32<T>(v);
-            xs[xs_index<T>(k, nch)] = v * to_f32(gw[k]);
-        });
-        ss = wave_sum(ss);
-        if (lane == 0) vs[W_SS + w] = __float_as_uint(ss);
-        cbarrier();
-        const float tot = __uint_as_float(vs[W_SS]) + __uint_as_float(vs[W_SS + 1]) + __uint_as_float(vs[W_SS + 2]) + __uint_as_float(vs[W_SS + 3]);
-        cbarrier();                           // (W_SS is rewritten by the next norm: everyone has read it)
-        return rsqrtf(tot / (float)H + p.eps);
-    };
-
-    // one product: walk the op's slots in stream order; this wave takes the blocks of its units (unit u -> wave u % 3) and carries the
-    // unit's accumulators across slots.  XT: the input vector is T values in `hvec` (down_proj) instead of fp32 planes in `xs`.
-    // one product: this wave takes the rows of its units (unit u -> wave u % 3), walking each row's 1 KiB blocks slot by slot.  Entering
-    // slot sg releases every earlier slot (freed = sg) and waits until the loader has published it.
-    int cur_slot = -1;
-    auto enter_slot = [&](int sg, int oi) {
-        if (sg == cur_slot) return;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // this wave's reads of the earlier slots are done
-        if (lane == 0) vs[W_FREED + w] = (unsigned)sg;
-        unsigned spins = 0;
-        while (!dead && (int)min(min(vs[W_READY], vs[W_READY + 1]), min(vs[W_READY + 2], vs[W_READY + 3])) <= sg) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) fail(0x500u + (unsigned)oi);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        cur_slot = sg;
-    };
-    // XT: the input vector is T values in `hvec` (down_proj) instead of fp32 planes in `xs`
-    auto product = [&](const Op& o, int oi, bool xt, auto&& finalize) {
-        const int nch = (o.rb / (int)sizeof(T)) / EPC;
-        const int rpu = o.pair ? 2 : 1, nunits = o.nrows / rpu;
-        for (int unit = w; unit < nunits; unit += NCONS) {
-            float acc[2] = {0.0f, 0.0f};
-            for (int r = 0; r < rpu; ++r) {
-                int gb = (unit * rpu + r) * o.bpr, pb = 0;
-                float a = 0.0f;
-                while (pb < o.bpr) {
-                    const int sg = o.slot0 + (gb >> 4), b0 = gb & (BPS - 1);
-                    const int nseg = min(o.bpr - pb, BPS - b0);
-                    enter_slot(sg, oi);
-                    const char* wp = ring + (size_t)(sg % NS) * SLOT + b0 * BLK + lane * 16;
-                    const int ci0 = pb * 64 + lane;
-                    if (xt) {
-                        const T* xp = hvec + (size_t)ci0 * EPC;
-                        for (int t = 0; t < nseg; ++t) {
-                            float wf[EPC], xf[EPC];
-                            chunk_to_f32<T>(*(const uint4*)(wp + t * BLK), wf);
-                            chunk_to_f32<T>(*(const uint4*)(xp + (size_t)t * 64 * EPC), xf);
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e) a = fmaf(wf[e], xf[e], a);
-                        }
-                    } else {
-                        const float* xp = xs + (size_t)ci0 * 4;
-                        for (int t = 0; t < nseg; ++t) {
-                            float wf[EPC], xf[EPC];
-                            chunk_to_f32<T>(*(const uint4*)(wp + t * BLK), wf);
-#pragma unroll
-                            for (int q = 0; q < PARTS; ++q) {
-                                const float4 v4 = *(const float4*)(xp + (size_t)q * nch * 4 + (size_t)t * 256);
-                                xf[4 * q] = v4.x; xf[4 * q + 1] = v4.y; xf[4 * q + 2] = v4.z; xf[4 * q + 3] = v4.w;
-                            }
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e) a = fmaf(wf[e], xf[e], a);
-                        }
-                    }
-                    pb += nseg; gb += nseg;
-                }
-                acc[r] = a;
-            }
-            const float r0 = wave_sum(acc[0]), r1 = o.pair ? wave_sum(acc[1]) : 0.0f;
-            if (lane == 0) finalize(unit, r0, r1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // the op's slots are all released (no wait: the next op's product enters its own)
-        if (lane == 0) vs[W_FREED + w] = (unsigned)(o.slot0 + o.nslots);
-        cur_slot = -1;
-    };
-    auto unit_done = [&]() {                  // (lane 0 of the finalising wave) the unit's value is in outbuf
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        lds_add_u32(sync0 + 4 * W_UNITS, 1u);
-    };
-
+    __syncthreads();
+    stamp(0);
     // (1) edge 0: merged attention output (qd values) -> xs, no norm
-    if (w == 0) stamp(0);
-    publish(0, perA, false);
+    publish(0, perA);
     {
         const int nch = qd / EPC;
         gather(0, qd, [&](int k, float v) { xs[xs_index<T>(k, nch)] = v; });
     }
-    cbarrier();
-    if (w == 0) stamp(1);
+    zero_part(op_o.nrows);
+    __syncthreads();
+    stamp(1);
     // (2) o_proj + residual -> x1
-    product(op_o, 0, false, [&](int unit, float r0, float) {
-        const int n = c * perH + unit;
-        outbuf[unit] = to_f32(from_f32<T>(r0 + to_f32(xres[n])));
-        unit_done();
-    });
-    units_target += perH;
-    if (w == 0) stamp(2);
+    product(op_o, op_gu, false);
+    __syncthreads();
+    if (tid < perH) outbuf[tid] = to_f32(from_f32<T>(row_sum(tid) + to_f32(xres[c * perH + tid])));
+    __syncthreads();
+    stamp(2);
     // (3) edge 1: x1 -> xres, xs = post_attention_layernorm weight * x1, rstd
-    publish(1, perH, true);
-    cbarrier();                               // every wave is past its last read of xs / xres (o_proj) before the gather rewrites them
-    const float rstd1 = gather_norm(1, (const T*)p.post_norm, true);
-    if (w == 0) stamp(3);
-    // (4) gate / up + SwiGLU -> hvec slice
-    product(op_gu, 1, false, [&](int unit, float r0, float r1) {
-        outbuf[unit] = to_f32(from_f32<T>(silu_f(r0 * rstd1) * (r1 * rstd1)));
-        unit_done();
-    });
-    units_target += perI;
-    if (w == 0) stamp(4);
+    publish(1, perH);
+    const float rstd1 = gather_norm(1, (const T*)p.post_norm, true, op_gu.nrows);
+    stamp(3);
+    // (4) gate / up + SwiGLU -> this CU's slice of the SwiGLU product
+    product(op_gu, op_dn, false);
+    __syncthreads();
+    if (tid < perI) outbuf[tid] = to_f32(from_f32<T>(silu_f(row_sum(2 * tid) * rstd1) * (row_sum(2 * tid + 1) * rstd1)));
+    __syncthreads();
+    stamp(4);
     // (5) edge 2: SwiGLU product (I values) -> hvec
-    publish(2, perI, true);
+    publish(2, perI);
     gather(2, I, [&](int k, float v) { hvec[k] = from_f32<T>(v); });
-    cbarrier();
-    if (w == 0) stamp(5);
+    zero_part(op_dn.nrows);
+    __syncthreads();
+    stamp(5);
     // (6) down_proj + residual -> x2 (also to global x: the next layer's launch / the head read it there)
-    product(op_dn, 2, true, [&](int unit, float r0, float) {
-        const int n = c * perH + unit;
-        const T vt = from_f32<T>(r0 + to_f32(xres[n]));
-        outbuf[unit] = to_f32(vt);
+    if (has_next) product(op_dn, op_qkv, true); else product(op_dn, op_dn, true);
+    __syncthreads();
+    if (tid < perH) {
+        const int n = c * perH + tid;
+        const T vt = from_f32<T>(row_sum(tid) + to_f32(xres[n]));
+        outbuf[tid] = to_f32(vt);
         ((T*)p.x)[n] = vt;
-        unit_done();
-    });
-    units_target += perH;
-    if (w == 0) stamp(6);
-    if (!has_next) {                          // last layer: x goes to the head; the launch still consumes its epoch
-        if (c == 0 && w == 0 && lane == 0) *p.seq = seq + 1u;
-        return;
     }
-    // (7) edge 3: x2 -> xs = next input_layernorm weight * x2, rstd
-    publish(3, perH, true);
-    cbarrier();
-    const float rstd2 = gather_norm(3, (const T*)p.next_norm, false);
-    if (w == 0) stamp(7);
-    // (8) the next layer's q | k | v rows (+ bias), un-roped: its attn_decode launch ropes q / k and appends k / v
-    product(op_qkv, 3, false, [&](int unit, float r0, float) {
-        const int n = c * perQ + unit;
-        float v = r0 * rstd2;
-        if (p.next_qkv_b) v += to_f32(((const T*)p.next_qkv_b)[n]);
-        ((T*)p.qkv_out)[n] = from_f32<T>(v);
-    });
-    if (w == 0) stamp(8);
-    if (c == 0 && w == 0 && lane == 0) *p.seq = seq + 1u;       // (every workgroup read seq before it could publish; the last edge is behind us)
+    __syncthreads();
+    stamp(6);
+    if (has_next) {
+        // (7) edge 3: x2 -> xs = next input_layernorm weight * x2, rstd
+        publish(3, perH);
+        const float rstd2 = gather_norm(3, (const T*)p.next_norm, false, op_qkv.nrows);
+        stamp(7);
+        // (8) the next layer's q | k | v rows (+ bias), un-roped: its attn_decode launch ropes q / k and appends k / v
+        product(op_qkv, op_qkv, false);
+        __syncthreads();
+        if (tid < perQ) {
+            const int n = c * perQ + tid;
+            float v = row_sum(tid) * rstd2;
+            if (p.next_qkv_b) v += to_f32(((const T*)p.next_qkv_b)[n]);
+            ((T*)p.qkv_out)[n] = from_f32<T>(v);
+        }
+        stamp(8);
+    }
+    if (c == 0 && tid == 0) *p.seq = seq + 1u;       // (every workgroup read seq before it could publish; the last edge is behind everyone)
 }
 
-template <typename T> constexpr int ring_slots() { return sizeof(T) == 2 ? 6 : 3; }
-template <typename T> size_t layer_lds_bytes(const DecodeLayerArgs& a) {
+template <typename T> size_t layer_lds_bytes(const DecodeLayerArgs& a, int G) {
     const int kx = a.H > a.qd ? a.H : a.qd;
-    return (size_t)ring_slots<T>() * SLOT + (size_t)kx * 4 + (size_t)a.H * sizeof(T) + (size_t)a.I * sizeof(T) + 128 * 4 + W_N * 4;
+    int nr = 2 * (a.I / G);
+    if (a.H / G > nr) nr = a.H / G;
+    if (a.qkv_dim / G > nr) nr = a.qkv_dim / G;
+    const size_t need = (size_t)kx * 4 + (size_t)a.H * sizeof(T) + (size_t)a.I * sizeof(T) + (size_t)nr * NW * 4 + 128 * 4 + NW * 4 + 64;
+    return need > LDS_FLOOR ? need : LDS_FLOOR;
 }
 
 }  // namespace
@@ -511,18 +435,19 @@ template <typename T> bool decode_layer_supported(const DecodeLayerArgs& a, int 
     auto rows_ok = [&](int K) { return (K * (int)sizeof(T)) % BLK == 0; };
     if (G < 1 || a.H % G || a.I % G || a.qd % G || a.qkv_dim % G) return false;
     if ((a.H / G) % VPG || (a.I / G) % VPG || (a.qd / G) % VPG) return false;
-    if (a.H / G > 64 || a.I / G > 128 || a.qd / G > 64 || a.qkv_dim / G > 128) return false;     // a CU's outputs fit outbuf / one wave publishes them
+    if (a.H / G > 64 || a.I / G > 128 || a.qd / G > 64 || a.qkv_dim / G > 128) return false;     // a CU's outputs fit outbuf; the merge spans <= 2 heads
     if (!rows_ok(a.H) || !rows_ok(a.I) || !rows_ok(a.qd)) return false;
+    if (a.H * (int)sizeof(T) / BLK > ROWMODE_MAX_BPR) return false;      // [gate | up] row pairs are dealt to the waves as whole rows
     if (a.H % Elt<T>::PER_CHUNK || a.I % Elt<T>::PER_CHUNK) return false;
-    return layer_lds_bytes<T>(a) <= (size_t)160 * 1024;
+    return layer_lds_bytes<T>(a, G) <= (size_t)160 * 1024;
 }
 template <typename T> void launch_decode_layer(hipStream_t s, const DecodeLayerArgs& a, int cus, hipEvent_t start, hipEvent_t stop) {
-    if (start || stop) hipExtLaunchKernelGGL((decode_layer_kernel<T, ring_slots<T>()>), dim3(cus), dim3(NTHREADS), layer_lds_bytes<T>(a), s, start, stop, 0, a);
-    else hipLaunchKernelGGL((decode_layer_kernel<T, ring_slots<T>()>), dim3(cus), dim3(NTHREADS), layer_lds_bytes<T>(a), s, a);
+    if (start || stop) hipExtLaunchKernelGGL((decode_layer_kernel<T>), dim3(cus), dim3(NTHREADS), layer_lds_bytes<T>(a, cus), s, start, stop, 0, a);
+    else hipLaunchKernelGGL((decode_layer_kernel<T>), dim3(cus), dim3(NTHREADS), layer_lds_bytes<T>(a, cus), s, a);
 }
 void decode_layer_init_attrs() {
-    set_max_lds((const void*)decode_layer_kernel<bf16, ring_slots<bf16>()>, 160 * 1024, NTHREADS);
-    set_max_lds((const void*)decode_layer_kernel<float, ring_slots<float>()>, 160 * 1024, NTHREADS);
+    set_max_lds((const void*)decode_layer_kernel<bf16>, 160 * 1024, NTHREADS);
+    set_max_lds((const void*)decode_layer_kernel<float>, 160 * 1024, NTHREADS);
 }
 template bool decode_layer_supported<bf16>(const DecodeLayerArgs&, int);
 template bool decode_layer_supported<float>(const DecodeLayerArgs&, int);

@@ -1242,7 +1242,7 @@ def test_full_depth_restart_turn_bf16_vs_fp32_engine():
     log = run_scenario(Recorder(m32), sc, preprocess=m32.get_vision_tower().image_processor.preprocess_array, device="cuda")
     assert len(log) == 9 and log[8]["views"] == 9 and log[8]["memory"]
     m32.close()
-    lm_head = torch.from_numpy(W.synth_tensor({s_.name: s_ for s_ in W.tensor_specs(TRUE)}["lm_head.weight"], SEED))
+    lm_head = torch.from_numpy(W.synth_state_dict(TRUE, SEED, only=["lm_head.weight"], workers=16)["lm_head.weight"])
     m16 = StreamVLNForCausalLM(TRUE, dtype=torch.bfloat16, max_envs=1, max_frames=9, max_positions=4096)
     m16.load_synthetic(SEED)
     m16.model.num_history = 8
