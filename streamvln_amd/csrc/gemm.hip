@@ -1104,6 +1104,8 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
     // Long-K products with fewer 256x256 tiles than CUs (down_proj at T = 1952: 8 x 14 tiles, 296 K tiles): two K slices per tile on the
     // 8-phase kernel + the slab reduce (which also emits the following RMSNorm) instead of 448 tiles of 128x128
     if constexpr (std::is_same<T, bf16>::value) {
+        // (M <= 256 long-K products -- down_proj of a steady prefill -- were tried on 256x256 tiles with 6 / 9 / 18 K slices in round 4, to halve
+        //  the re-staging of their 8 MB activation panel: prefill +0.03 .. +0.4 ms per turn in the in-turn A/B, so they stay on 128x128 split-K)
         const int ktiles = (a.K / EPC + 7) / 8;
         const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0) && (size_t)2 * a.M * a.N <= a.ws_elems;
         if (((tilesbig >= 96 && tilesbig <= 128 && a.M > 512 && ktiles >= 128 && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 258) &&

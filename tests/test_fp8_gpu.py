@@ -66,8 +66,8 @@ def _oracle_runs(cfg, sc, modes, seeds, workers=16):
     """{(mode, seed): [(ids, hidden [n,H], margins, cache_len) per turn]} from the emulating CPU oracle; the dequantised weight copies are
     shared by all modes"""
     from oracle import streamvln_oracle as O
-    from streamvln_amd import weights as W
-    sd = W.synth_state_dict(cfg, SEED, workers=workers)
+    from util import synth_weights
+    sd = synth_weights(cfg, SEED, workers)
     pre = lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb))
     shared = {}
     out = {}
@@ -82,7 +82,7 @@ def _oracle_runs(cfg, sc, modes, seeds, workers=16):
             out[(mode, seed)] = [(r["out"].sequences[0].tolist(), r["out"].hidden.numpy().copy(), list(r["out"].margins), r["out"].cache_len)
                                  for r in log]
             del orc, log
-    del sd, shared
+    del shared
     gc.collect()
     return out
 
@@ -133,7 +133,7 @@ def test_fp8_modes_vs_emulating_oracle(name):
     # (an episode stops being comparable at its first low-margin id flip: the w8a8 modes need more prompt seeds for their 8 rows)
     modes = ("decode", "gemm", "both")
     # (TRUE4: every oracle episode costs ~15 s of host time; the w8a8 rows of 'gemm' and 'both' are counted together)
-    seeds_of = ({"decode": (7, 11), "gemm": (7, 11, 13, 17), "both": (7, 11, 13, 17)} if name == "tiny_episode"
+    seeds_of = ({"decode": (7,), "gemm": (7, 11, 13), "both": (7, 11)} if name == "tiny_episode"
                 else {"decode": (7,), "gemm": (7, 11, 13), "both": (7, 11)})
     exp = _oracle_runs(cfg, sc, modes, seeds_of)
     m = StreamVLNForCausalLM(cfg, dtype=torch.bfloat16, max_envs=1, max_frames=1 + sc["num_history"], max_positions=2048)
@@ -159,9 +159,9 @@ def test_fp8_modes_vs_emulating_oracle(name):
 
 def test_fp8_full_depth_decode_weights_vs_emulating_oracle():
     """The benchmarked instantiation (26 + 28 layers, true width) with e4m3 decode weights against the emulation run live: the first turn
-    (T = 376) with 8 tokens -- the e4m3 GEMV path's own end-to-end rows at full depth (7 of the 8 rows are decode rows)."""
+    (T = 376) with 6 tokens -- the e4m3 GEMV path's own end-to-end rows at full depth (5 of the 6 rows are decode rows)."""
     from streamvln_amd.config import TRUE
-    sc = dict(SCENARIOS["true4_episode"], cfg=TRUE, steps=4, max_new=8, eos_mod=0)
+    sc = dict(SCENARIOS["true4_episode"], cfg=TRUE, steps=4, max_new=6, eos_mod=0)
     t0 = time.time()
     exp = _oracle_runs(TRUE, sc, ("decode",), (7,))
     t_o = time.time() - t0
@@ -175,8 +175,8 @@ def test_fp8_full_depth_decode_weights_vs_emulating_oracle():
     print(line)
     _note("fp8_vs_emulation", line)
     _note_json("streamvln_qwen2_7b/decode", {"rows": rows, "decode_rows": dec_rows, "ids_asserted": asserted, "hidden_rel_l2_worst": round(worst, 5),
-                                            "bound": W8_REL[TRUE.name], "sample": "first turn T = 376, 8 tokens, 26 + 28 layers"})
-    assert rows >= 4 and dec_rows >= 3, (rows, dec_rows)        # (8 rows unless a token below the margin flips; 8 in the committed run)
+                                            "bound": W8_REL[TRUE.name], "sample": "first turn T = 376, 6 tokens, 26 + 28 layers"})
+    assert rows >= 4 and dec_rows >= 3, (rows, dec_rows)        # (6 rows unless a token below the margin flips)
 
 
 def test_fp8_full_depth_prefill_layers_teacher_forced_and_error_curve():

@@ -42,3 +42,17 @@ def assert_close(got, exp, dtype, what=""):
 
 def load_golden(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+_SD_CACHE = {}
+
+
+def synth_weights(cfg, seed, workers=16):
+    """synthetic state dict of `cfg` (fp32 numpy, bf16-rounded values), built once per test session: the 7.6 B values of the true-size
+    model take ~30 s on the box's host threads, and three live-oracle tests use them (only the latest configuration is kept)"""
+    from streamvln_amd import weights as W
+    key = (cfg.name, seed)
+    if key not in _SD_CACHE:
+        _SD_CACHE.clear()
+        _SD_CACHE[key] = W.synth_state_dict(cfg, seed, workers=workers)
+    return _SD_CACHE[key]

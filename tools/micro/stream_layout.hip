@@ -63,6 +63,35 @@ __global__ __launch_bounds__(1024) void stream_kernel(const char* base, size_t t
     if (threadIdx.x == 0 && smem[3] == 123 && smem[99] == 45) sink[1] = 1;
 }
 
+// MIXED: what the M ~ 212 GEMM does to a CU -- waves 0-3 stream the workgroup's share of a cold 448 MB weight region (LDS-DMA, non-temporal),
+// waves 4-7 meanwhile re-read ONE 1.5 MB activation panel (the same for every workgroup: L2-resident) `a_ratio` times as many bytes, default
+// cache policy.  Do the two streams share one delivery limit (the weights slow down), or do they add?
+template <int DEPTH>
+__global__ __launch_bounds__(512) void mixed_kernel(const char* wbase, size_t wtotal, const char* abase, size_t abytes, int a_ratio, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t G = gridDim.x, c = blockIdx.x;
+    const size_t per_wg = wtotal / G, nblk = per_wg / 1024;
+    char* ring = smem + (size_t)wave * DEPTH * 1024;
+    size_t issued = 0;
+    if (wave < 4) {
+        for (size_t b = wave; b < nblk; b += 4, ++issued) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wbase + c * per_wg + b * 1024 + lane * 16), (lds_ptr_t)(ring + (issued % DEPTH) * 1024), 16, 0, 2);
+            if (issued % 8 == 7 && issued + 1 >= DEPTH) wait_vm<DEPTH - 8>();
+        }
+    } else {
+        const size_t ablk = abytes / 1024, n = nblk * (size_t)a_ratio;
+        for (size_t b = wave - 4; b < n; b += 4, ++issued) {
+            const size_t ab = (b + c * 37) % ablk;                    // every workgroup walks the panel from its own offset
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + ab * 1024 + lane * 16), (lds_ptr_t)(ring + (issued % DEPTH) * 1024), 16, 0, 0);
+            if (issued % 8 == 7 && issued + 1 >= DEPTH) wait_vm<DEPTH - 8>();
+        }
+    }
+    wait_vm<0>();
+    __syncthreads();
+    if (threadIdx.x == 0 && smem[3] == 123 && smem[99] == 45) sink[1] = 1;
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     int cus = 0;
@@ -109,6 +138,25 @@ int main() {
             snprintf(what, sizeof(what), "register loads nt, %s%zu B, %d waves", gran ? "INTERLEAVED at " : "BLOCKED ", gran, waves);
             run(what, stream_kernel<16, false>, waves, 0, gran);
         }
+    }
+    // mixed streams: weights (HBM) + a shared L2-resident panel
+    CK(hipFuncSetAttribute((const void*)mixed_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    char* panel;
+    CK(hipMalloc(&panel, (size_t)3 << 20));
+    CK(hipMemset(panel, 2, (size_t)3 << 20));
+    for (int a_ratio : {0, 1, 2, 4}) {
+        float best = 1e9f;
+        for (int r = 0; r < 6; ++r) {
+            const char* p = buf + (size_t)(r % ncopy) * copy;
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(mixed_kernel<16>, dim3(cus), dim3(512), (size_t)8 * 16 * 1024, 0, p, copy, panel, (size_t)1536 * 1024, a_ratio, sink);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r && ms < best) best = ms;
+        }
+        printf("MIXED 4 weight waves (HBM, nt) + 4 panel waves (1.5 MB, L2-resident), panel bytes = %d x weight bytes: best %7.1f us -> weights %5.2f TB/s (%5.1f GB/s per CU), "
+               "panel %5.2f TB/s, together %5.2f TB/s\n", a_ratio, best * 1e3, copy / best / 1e9, copy / best / 1e6 / cus, copy * (double)a_ratio / best / 1e9,
+               copy * (1.0 + a_ratio) / best / 1e9);
     }
     return 0;
 }
