@@ -13,8 +13,9 @@
 //   S^T = K.Q^T on MFMA with the key on the accumulator ROW and the query on the LANE, so the
 //   online-softmax max/sum over keys is an in-lane reduction + ONE cross-half wavefront shuffle
 //   (__shfl_xor 32); P stays in registers and feeds the second MFMA directly as its B operand.
-// Split-KV (decode, steady prefill with few row blocks, one-frame ViT): grid.z splits write (m, l, unnormalised O)
-// partials (rows padded to 16 bytes, float4 stores); attn_combine_kernel merges them.
+// Split-KV (decode, steady prefill with few row blocks): grid.z splits write (m, l, unnormalised O)
+// partials (rows padded to 16 bytes, float4 stores); attn_combine_kernel merges them.  One-frame ViT: the key split stays inside the
+// workgroup (KG key groups of 2 waves, merged through LDS).
 //
 // Roofline: decode = HBM (KV bytes 2*nkv*hd*len*sizeof(T) per layer); prefill/ViT = MFMA by flops, but at these sizes
 // (<= 1.2 waves per SIMD) measured ~3 us of exposed latency per 64-key tile: the softmax VALU work, the MFMA chains and the
@@ -64,21 +65,25 @@ template <int I, int N, typename F> SVLN_DEV void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-template <typename T, int HD, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1) void attn_kernel(AttnArgs p) {
+// KG > 1 (one-frame ViT): the workgroup is KG key groups of WAVES waves; group kg walks key tiles kg, kg + KG, ... of the SAME 32 * WAVES query
+// rows through its own K / Vt tile pair in LDS, so KG tiles are in flight per workgroup at once, and the groups' (m, l, O) are merged through
+// LDS at the end: the split-KV partials never leave the CU and there is no combine launch.
+template <typename T, int HD, int WAVES, int KG = 1, bool PF = true>
+__global__ __launch_bounds__(WAVES * 64 * KG, (KG == 1 && WAVES == 4 && sizeof(T) == 2) ? 2 : 1) void attn_kernel(AttnArgs p) {
     using G = AttnGeom<T, HD>;
-    constexpr int NT = WAVES * 64;
+    constexpr int NT = WAVES * 64;              // threads of one key group: they stage its tiles
     constexpr int EPC = G::EPC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + G::K_TILE_BYTES;
+    const int kg = KG == 1 ? 0 : (int)threadIdx.x / NT;
+    char* sK = smem + kg * (G::K_TILE_BYTES + G::V_TILE_BYTES);
+    char* sV = sK + G::K_TILE_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = KG == 1 ? (int)threadIdx.x : (int)threadIdx.x - kg * NT, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int kh = blockIdx.y;
     const int frame = kh / p.hpf, head0 = (kh % p.hpf) * p.G;
     // first page id is independent of kv_len: fetch both scalars together (one round trip instead of two)
-    const int kt0 = blockIdx.z * p.tiles_per_split;
+    const int kt0 = blockIdx.z * p.tiles_per_split + kg;
     const int page0 = p.page_table ? p.page_table[kt0] : kt0;
     const int kv_len = p.dyn_kv_len ? *p.dyn_kv_len : p.kv_len;
     const int P = p.dyn_kv_len ? kv_len - p.T : p.P;
@@ -106,8 +111,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
         const int last_pos = P + last_row / p.G;
         tiles = min(tiles, (last_pos >> 6) + 1);
     }
-    const int kt_begin = blockIdx.z * p.tiles_per_split;
-    const int kt_end = min(tiles, kt_begin + p.tiles_per_split);
+    const int kt_begin = blockIdx.z * p.tiles_per_split + kg;
+    const int kt_end = min(tiles, (int)blockIdx.z * p.tiles_per_split + p.tiles_per_split);
+    const int n_iter = (kt_end - (int)blockIdx.z * p.tiles_per_split + KG - 1) / KG;       // uniform over the workgroup (barriers)
 
     const float scale2 = p.scale * 1.4426950408889634f;      // scores are kept in the log2 domain (m too)
     f32x16 O[G::DT];
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
 
     // 4-wave workgroups (prefill / ViT): the next tile's K / Vt loads are issued into registers right after the barrier
     // that publishes the current tile and stay in flight under its MFMAs (one tile of HBM/L2 latency hidden per tile).
-    constexpr bool PREFETCH = WAVES == 4;
+    constexpr bool PREFETCH = WAVES == 4 || (KG > 1 && PF);
     constexpr int KTOT_ = 64 * G::HDC, VTOT_ = G::VROWS * G::VC;
     constexpr int KLP = (KTOT_ + NT - 1) / NT, VLP = (VTOT_ + NT - 1) / NT;
     uint4 pk[PREFETCH ? KLP : 1], pv[PREFETCH ? VLP : 1];
@@ -166,14 +172,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
     };
     if (PREFETCH && kt_begin < kt_end) load_regs(kt_begin);
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    for (int it = 0; it < n_iter; ++it) {
+        const int kt = kt_begin + it * KG;
+        const bool act = KG == 1 || kt < kt_end;        // (a key group past its last tile only keeps the barriers)
         const int page = kt == kt0 ? page0 : (p.page_table ? p.page_table[kt] : kt);
         const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
         const char* gV = (const char*)p.Vpool + (size_t)page * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
         // ---- stage K and Vt tiles: coalesced 16-byte loads issued in batches (all in flight before the first
         //      dependent LDS write), swizzled LDS writes
         if (PREFETCH) {
-            store_regs();
+            if (act) store_regs();
         } else {
             constexpr int KTOT = 64 * G::HDC, VTOT = G::VROWS * G::VC, B = WAVES == 1 ? 4 : 8;
             constexpr int KL = (KTOT + NT - 1) / NT, VL = (VTOT + NT - 1) / NT;
@@ -218,7 +226,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
             }
         }
         __syncthreads();
-        if (PREFETCH && kt + 1 < kt_end) load_regs(kt + 1);
+        if (PREFETCH && kt + KG < kt_end) load_regs(kt + KG);
+        if (act) {
 
         // ---- S^T[j] = K_tile[j*32 .. j*32+31] . Q^T   (rows = keys, col = this lane's query)
         f32x16 S[2];
@@ -324,10 +333,56 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && sizeof(T) == 2) ? 2 : 1)
                     }
                 }
         }
+        }
         __syncthreads();
     }
 
     l += __shfl_xor(l, 32, 64);
+    if constexpr (KG > 1) {
+        // ---- merge of the key groups (the loop ended on a barrier: the tiles are dead).  (m, l) of every group and row -> each lane scales its
+        // O by exp2(m - M) / L -> fp32 rows in LDS -> all threads sum the KG rows and store 4 channels each.
+        constexpr int ROWS = WAVES * 32, OP = HD + ATTN_PART_PAD;
+        float* sML = (float*)smem;                                  // [KG][ROWS] x (m, l)
+        float* sO = (float*)(smem + KG * ROWS * 8);                 // [KG][ROWS][OP]
+        const int rowl = wave * 32 + r;
+        if (h == 0) *(float2*)(sML + (kg * ROWS + rowl) * 2) = make_float2(m, l);
+        __syncthreads();
+        float M = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) M = fmaxf(M, sML[(g * ROWS + rowl) * 2]);
+        float L = 0.0f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const float2 ml = *(const float2*)(sML + (g * ROWS + rowl) * 2);
+            L += ml.x == -INFINITY ? 0.0f : ml.y * fast_exp2(ml.x - M);
+        }
+        const float f = (m == -INFINITY || !(L > 0.0f)) ? 0.0f : fast_exp2(m - M) / L;
+        float* od = sO + (size_t)(kg * ROWS + rowl) * OP;
+#pragma unroll
+        for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int dd = d * 32 + acc_row(e4 * 4, lane);
+                if (dd < HD) *(float4*)(od + dd) = make_float4(O[d][4 * e4] * f, O[d][4 * e4 + 1] * f, O[d][4 * e4 + 2] * f, O[d][4 * e4 + 3] * f);
+            }
+        __syncthreads();
+        for (int q = threadIdx.x; q < ROWS * (HD / 4); q += NT * KG) {
+            const int row = q / (HD / 4), c4 = q - row * (HD / 4);
+            const int rho_o = blockIdx.x * ROWS + row;
+            if (rho_o >= rows_total) continue;
+            float4 acc = *(const float4*)(sO + (size_t)row * OP + c4 * 4);
+#pragma unroll
+            for (int g = 1; g < KG; ++g) {
+                const float4 v = *(const float4*)(sO + (size_t)(g * ROWS + row) * OP + c4 * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            const int qi_o = rho_o / p.G, qg_o = rho_o - qi_o * p.G;
+            T* orow = (T*)p.O + (size_t)(frame * p.T + qi_o) * p.o_stride + (size_t)(head0 + qg_o) * HD + c4 * 4;
+            if (sizeof(T) == 2) *(uint2*)orow = make_uint2(pack_bf16x2(acc.x, acc.y), pack_bf16x2(acc.z, acc.w));
+            else *(float4*)orow = acc;
+        }
+        return;
+    }
     if (!valid) return;
 
     if (p.nsplit > 1) {
@@ -590,6 +645,25 @@ template <typename T, int HD, int WAVES> void launch_attn_t(hipStream_t s, const
     const size_t lds = G::K_TILE_BYTES + G::V_TILE_BYTES;
     hipLaunchKernelGGL((attn_kernel<T, HD, WAVES>), grid, block, lds, s, a);
 }
+// key groups inside the workgroup (a.key_groups > 1): 64 query rows x KG groups, one pass over all key tiles, no partials.
+// One ViT frame, bf16, measured (tools/kbench.py attn under rocprofv3): split-KV 3 + combine 15.6 + 7.4 us; 4 groups with the register
+// prefetch 14.3; 4 groups without it 19.3; 6 groups without 20.1; 6 groups with it 34.8 (12 waves leave 168 VGPRs: 72 spilled).
+// fp32 (the verification engine): 3 groups, no prefetch (its tiles are twice the bytes: LDS and registers).
+template <typename T> struct VitGroups { static constexpr int KG = sizeof(T) == 2 ? 4 : 3; static constexpr bool PF = sizeof(T) == 2; };
+template <typename T, int HD, int KG_> struct GroupGeom {
+    using G = AttnGeom<T, HD>;
+    static constexpr int WAVES = 2, ROWS = WAVES * 32;
+    static constexpr int KG = KG_;
+    static constexpr size_t TILES = (size_t)KG * (G::K_TILE_BYTES + G::V_TILE_BYTES);
+    static constexpr size_t MERGE = (size_t)KG * ROWS * (8 + (HD + ATTN_PART_PAD) * 4);
+    static constexpr size_t LDS = TILES > MERGE ? TILES : MERGE;
+};
+template <typename T, int HD, int KG, bool PF> void launch_attn_groups(hipStream_t s, const AttnArgs& a) {
+    using GG = GroupGeom<T, HD, KG>;
+    const int rows = a.T * a.G;
+    dim3 grid((rows + GG::ROWS - 1) / GG::ROWS, a.n_kv_total, 1), block(GG::WAVES * 64 * GG::KG);
+    hipLaunchKernelGGL((attn_kernel<T, HD, GG::WAVES, GG::KG, PF>), grid, block, GG::LDS, s, a);
+}
 
 }  // namespace
 
@@ -597,6 +671,11 @@ template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, in
     if (head_dim == 128 && waves == 1 && a.fuse_rope_append && a.T == 1) {
         using G = AttnGeom<T, 128>;
         hipLaunchKernelGGL((attn_decode_kernel<T>), dim3(a.n_kv_total, a.nsplit, a.batch > 0 ? a.batch : 1), dim3(256), G::K_TILE_BYTES + G::V_TILE_BYTES, s, a);
+        return;
+    }
+    if (a.key_groups > 1) {
+        if (a.nsplit != 1 || head_dim != 72 || a.key_groups != attn_key_groups<T>()) throw std::runtime_error("attention: key groups need head_dim 72, nsplit 1 and key_groups == attn_key_groups<T>()");
+        launch_attn_groups<T, 72, VitGroups<T>::KG, VitGroups<T>::PF>(s, a);
         return;
     }
     if (head_dim == 128) {
@@ -619,7 +698,12 @@ void attention_init_attrs() {
     set_max_lds((const void*)attn_decode_kernel<float>, AttnGeom<float, 128>::K_TILE_BYTES + AttnGeom<float, 128>::V_TILE_BYTES);
     attn_attr<bf16, 128, 1>(); attn_attr<bf16, 128, 4>(); attn_attr<bf16, 72, 1>(); attn_attr<bf16, 72, 4>();
     attn_attr<float, 128, 1>(); attn_attr<float, 128, 4>(); attn_attr<float, 72, 1>(); attn_attr<float, 72, 4>();
+    set_max_lds((const void*)attn_kernel<bf16, 72, 2, VitGroups<bf16>::KG, VitGroups<bf16>::PF>, GroupGeom<bf16, 72, VitGroups<bf16>::KG>::LDS);
+    set_max_lds((const void*)attn_kernel<float, 72, 2, VitGroups<float>::KG, VitGroups<float>::PF>, GroupGeom<float, 72, VitGroups<float>::KG>::LDS);
 }
+template <typename T> int attn_key_groups() { return VitGroups<T>::KG; }
+template int attn_key_groups<bf16>();
+template int attn_key_groups<float>();
 template void launch_attention<bf16>(hipStream_t, const AttnArgs&, int, int);
 template void launch_attention<float>(hipStream_t, const AttnArgs&, int, int);
 template void launch_attention_combine<bf16>(hipStream_t, const AttnArgs&, int);

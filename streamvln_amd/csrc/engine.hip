@@ -486,9 +486,12 @@ public:
         a.Q = q; a.q_stride = ld; a.O = out; a.o_stride = o_stride; a.Kpool = vkpool; a.Vpool = vvpool; a.page_table = nullptr;
         a.n_kv_total = F * vheads; a.hpf = vheads; a.G = 1; a.T = S; a.P = 0; a.kv_len = S; a.dyn_kv_len = nullptr;
         a.scale = 1.0f / sqrtf((float)vhd); a.causal = 0; a.nsplit = 1; a.tiles_per_split = vtiles; a.part = attn_part; a.rows_pad = 0;
-        // one frame = 6 row blocks x 16 heads = 96 workgroups: split the 12 key tiles 3 ways to fill the chip
+        // one frame = 6 row blocks x 16 heads = 96 workgroups of the plain kernel: too few to fill the chip
         const int wgs = ((S + 127) / 128) * F * vheads, rows_pad = ((S + 127) / 128) * 128;
         // (measured: 6 splits are slower than 3 -- the fp32 partials double -- and unsplit is 35 us against 18 + 8 for split + combine)
+        // one frame, head_dim 72: the key split stays inside the workgroup (key groups merged through LDS): 14.3 us against 15.6 + 7.4
+        if (wgs < 192 && vtiles >= 6 && vhd == 72) { a.key_groups = attn_key_groups<T>(); return a; }
+        // (other head dims)
         if (wgs < 192 && vtiles >= 6 && (size_t)3 * F * vheads * rows_pad * (vhd + ATTN_PART_PAD) <= attn_part_elems) {
             a.nsplit = 3; a.tiles_per_split = (vtiles + 2) / 3; a.rows_pad = rows_pad;
         }
