@@ -10,6 +10,7 @@ import torch
 
 from scenarios import SCENARIOS, SEED, apply_knobs, eos_ids, run_scenario
 from streamvln_amd.model import StreamVLNForCausalLM
+import util
 from util import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -491,7 +492,7 @@ def test_ragged_turns_vs_live_oracle():
     m = StreamVLNForCausalLM(cfg, dtype=torch.float32, max_envs=1, max_frames=3, max_positions=2048)
     m.load_synthetic(SEED)
     m.model.num_history = 2
-    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=2)
+    orc = O.OracleStreamVLN(cfg, util.synth_weights(cfg, SEED), num_history=2)
     pre = m.get_vision_tower().image_processor.preprocess_array
     frames = torch.stack([pre(synthetic_frame(0, s)) for s in range(5)])               # [5,3,384,384]
 
@@ -658,7 +659,7 @@ def test_long_horizon_single_window_vs_live_oracle():
     hid = []
     pre = m.get_vision_tower().image_processor.preprocess_array
     log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
-    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=8)
+    orc = O.OracleStreamVLN(cfg, util.synth_weights(cfg, SEED), num_history=8)
     log_o = run_scenario(orc, sc, preprocess=pre)
     assert len(log_g) == len(log_o) == 16
     for t, (a, b) in enumerate(zip(log_g, log_o)):
@@ -685,7 +686,7 @@ def test_memory_prune_extension_vs_live_oracle():
     hid = []
     pre = m.get_vision_tower().image_processor.preprocess_array
     log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
-    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=sc["num_history"], memory_keep=keep)
+    orc = O.OracleStreamVLN(cfg, util.synth_weights(cfg, SEED), num_history=sc["num_history"], memory_keep=keep)
     log_o = run_scenario(orc, sc, preprocess=pre)
     assert len(log_g) == len(log_o)
     mem_turns = 0
@@ -723,7 +724,7 @@ def test_config3_long_window_with_pruned_memory_vs_live_oracle():
     hid = []
     pre = m.get_vision_tower().image_processor.preprocess_array
     log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
-    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=8, memory_keep=keep)
+    orc = O.OracleStreamVLN(cfg, util.synth_weights(cfg, SEED), num_history=8, memory_keep=keep)
     log_o = run_scenario(orc, sc, preprocess=pre)
     assert len(log_g) == len(log_o) == 18
     for t, (a, b) in enumerate(zip(log_g, log_o)):
@@ -770,7 +771,7 @@ def test_from_pretrained_safetensors_equals_synthetic(tmp_path):
     from streamvln_amd import weights as W
     sc = SCENARIOS["tiny_episode"]
     cfg = sc["cfg"]
-    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in W.synth_state_dict(cfg, SEED).items()}
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in util.synth_weights(cfg, SEED).items()}
     names = sorted(sd)
     save_file({k: sd[k] for k in names[: len(names) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
     save_file({k: sd[k] for k in names[len(names) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
@@ -854,7 +855,7 @@ def _oracle_env_logs(sc, n_envs, lengths, n_turns, env_steps=None):
     from streamvln_amd.agent import StreamingAgent
     from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
     cfg = sc["cfg"]
-    sd = W.synth_state_dict(cfg, SEED)
+    sd = util.synth_weights(cfg, SEED)
     logs = []
     for e in range(n_envs):
         orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"])
@@ -968,7 +969,7 @@ def test_repetition_penalty_solo_batch_and_scheduler_agree_with_oracle():
     m.load_synthetic(SEED)
     m.model.num_history = 2
     m.generation_config.repetition_penalty = pen
-    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=2)
+    orc = O.OracleStreamVLN(cfg, util.synth_weights(cfg, SEED), num_history=2)
     orc.generation_config.repetition_penalty = pen
     reqs, exp = [], []
     for e in range(NE):
@@ -1104,7 +1105,7 @@ def test_generation_config_keys(tmp_path):
     from streamvln_amd import weights as W
     sc = SCENARIOS["tiny_episode"]
     cfg = sc["cfg"]
-    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in W.synth_state_dict(cfg, SEED).items()}
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in util.synth_weights(cfg, SEED).items()}
     save_file(sd, str(tmp_path / "model.safetensors"))
     json.dump({"do_sample": True, "temperature": 0.7, "top_p": 0.8, "top_k": 20, "repetition_penalty": 1.05, "eos_token_id": [7, 9],
                "bos_token_id": 1, "pad_token_id": 1}, open(tmp_path / "generation_config.json", "w"))
@@ -1130,7 +1131,7 @@ def test_config0_window_16_4_4_vs_live_oracle():
     hid = []
     pre = m.get_vision_tower().image_processor.preprocess_array
     log_g = run_scenario(m, sc, preprocess=pre, device="cuda", on_turn=lambda t, r: hid.append(m.last_hidden()))
-    orc = O.OracleStreamVLN(cfg, W.synth_state_dict(cfg, SEED), num_history=4)
+    orc = O.OracleStreamVLN(cfg, util.synth_weights(cfg, SEED), num_history=4)
     log_o = run_scenario(orc, sc, preprocess=pre)
     assert len(log_g) == len(log_o) == 10
     assert [r["views"] for r in log_g] == [1, 1, 1, 1, 5, 1, 1, 1, 5, 1] and [bool(r["memory"]) for r in log_g] == [v == 5 for v in [1, 1, 1, 1, 5, 1, 1, 1, 5, 1]]

@@ -49,10 +49,13 @@ _SD_CACHE = {}
 
 def synth_weights(cfg, seed, workers=16):
     """synthetic state dict of `cfg` (fp32 numpy, bf16-rounded values), built once per test session: the 7.6 B values of the true-size
-    model take ~30 s on the box's host threads, and three live-oracle tests use them (only the latest configuration is kept)"""
+    model take ~30 s on the box's host threads, and three live-oracle tests use them (the four latest configurations are kept)"""
     from streamvln_amd import weights as W
     key = (cfg.name, seed)
     if key not in _SD_CACHE:
-        _SD_CACHE.clear()
+        while len(_SD_CACHE) >= 4:                   # (true size = 30 GB of fp32; the box has 270 GB of host memory)
+            _SD_CACHE.pop(next(iter(_SD_CACHE)))
         _SD_CACHE[key] = W.synth_state_dict(cfg, seed, workers=workers)
+    else:
+        _SD_CACHE[key] = _SD_CACHE.pop(key)          # most recently used last
     return _SD_CACHE[key]
