@@ -423,6 +423,10 @@ class OracleStreamVLN:
         self.cfg = cfg
         self.fp8 = fp8                          # opt-in e4m3 emulation (extension, no reference counterpart); None = the reference's arithmetic
         self.layer_taps: List[torch.Tensor] = []   # last-row residual stream after every layer of the latest prefill (test tap)
+        # test mode (no reference counterpart): a queue of token lists, one per coming generate() call -- the call decodes exactly those tokens
+        # (teacher forcing) while `own_picks` keeps what this model would have picked at each step and `margins` its top-1 / top-2 gap
+        self.teacher_tokens: List[List[int]] = []
+        self.own_picks: List[int] = []
         # the two call-time knobs of the reference, under the reference's attribute names
         self.config = SimpleNamespace(tokenizer_model_max_length=None)          # stream_video_vln.py:241
         self.generation_config = SimpleNamespace(repetition_penalty=1.0)        # GenerationConfig default
@@ -466,10 +470,15 @@ class OracleStreamVLN:
         h = qwen2_forward(w, cfg, E[P:], P, cache, self.fp8, "prefill", self.layer_taps)[-1]
         out, hid, margins = [], [], []
         pen = float(getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0)
+        forced = self.teacher_tokens.pop(0) if self.teacher_tokens else None
+        self.own_picks = []
         while True:
             tok, margin = greedy_pick(repetition_penalty(lm_logits(w, h, self.fp8), out, pen))
+            self.own_picks.append(tok)
+            if forced is not None:                           # test mode: continue from the given token, keep this model's own pick and margin
+                tok = int(forced[len(out)])
             out.append(tok); hid.append(h.clone()); margins.append(margin)
-            if tok in eos or len(out) >= max_new_tokens:
+            if (forced is not None and len(out) >= len(forced)) or (forced is None and (tok in eos or len(out) >= max_new_tokens)):
                 break
             x = w["model.embed_tokens.weight"][tok][None]
             h = qwen2_forward(w, cfg, x, len(cache), cache, self.fp8, "decode")[-1]

@@ -156,3 +156,27 @@ def test_fp8_emulation_arithmetic_and_neutral_mode():
     assert (0.0 < d < 0.3) or runs["decode"][0][0][0] != runs["plain"][0][0][0]     # ... the decode rows move (unless the e4m3 lm_head already changed the fed token)
     gmm = np.linalg.norm(runs["gemm"][0][1][0] - h0[0]) / np.linalg.norm(h0[0])
     assert 0.005 < gmm < 0.3, gmm
+
+
+def test_teacher_tokens_mode_keeps_the_models_own_picks():
+    """OracleStreamVLN.teacher_tokens (test mode): a turn decodes the given tokens; with the model's own tokens nothing changes, with a
+    changed second token the first row, the first pick and its margin stay and the sequence is the forced one."""
+    sc = SCENARIOS["tiny_episode"]
+    cfg = sc["cfg"]
+    pre = lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb))
+    sd = W.synth_state_dict(cfg, SEED)
+    free = run_scenario(O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"]), sc, preprocess=pre, steps=1)[0]["out"]
+    ids = free.sequences[0].tolist()
+    assert len(ids) >= 2
+    orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"])
+    orc.teacher_tokens = [list(ids)]
+    same = run_scenario(orc, sc, preprocess=pre, steps=1)[0]["out"]
+    assert same.sequences[0].tolist() == ids and orc.own_picks == ids and orc.teacher_tokens == []
+    assert torch.equal(same.hidden, free.hidden) and same.margins == free.margins and same.cache_len == free.cache_len
+    forced = [ids[0], (ids[1] + 1) % cfg.vocab] + ids[2:]
+    orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"])
+    orc.teacher_tokens = [forced]
+    other = run_scenario(orc, sc, preprocess=pre, steps=1)[0]["out"]
+    assert other.sequences[0].tolist() == forced and orc.own_picks[:2] == ids[:2]
+    assert torch.equal(other.hidden[:2], free.hidden[:2]) and other.margins[:2] == free.margins[:2]
+    assert len(forced) < 3 or not torch.equal(other.hidden[2], free.hidden[2])
