@@ -100,7 +100,8 @@ class StreamingAgent:
         V = len(images)
         self._pending = {"step_id": self.step_id, "n_inputs": int(ids.shape[1]), "views": V, "memory": bool(with_memory)}
         # torch.stack(images) of the reference (streamvln_eval.py:313-321); one view: the same values as a view of the frame (no copy kernel)
-        stacked = images[0].unsqueeze(0) if V == 1 else self._stack_views(images)
+        self._prime_stack(images[0])
+        stacked = images[0].unsqueeze(0) if V == 1 else torch.stack(images)
         aux = self._aux.get(V)
         if aux is None:              # depths / poses / intrinsics are built by the reference callers and ignored by the model
             aux = self._aux[V] = (torch.zeros(1, V, 1, 1), torch.zeros(1, V, 4, 4), torch.zeros(1, V, 4, 4))
@@ -112,15 +113,14 @@ class StreamingAgent:
             "return_dict_in_generate": True, "past_key_values": self.past_key_values, "eos_token_ids": self.eos_token_ids,
         }
 
-    def _stack_views(self, images):
-        """torch.stack(images) (streamvln_eval.py:313-321).  torch loads the copy kernel for an N-input stack at its first use: the 9-view
-        stack of the first window restart of a process took 8.5 ms (0.1 ms at every later restart).  The first turn of an agent therefore
-        runs that stack once on its own frame, so the one-time cost sits at the start of the first episode."""
+    def _prime_stack(self, frame):
+        """torch loads the copy kernel of an N-input torch.stack at its first use: the 9-view stack of the first window restart of a process
+        took 8.5-18 ms (0.1 ms at every later restart).  The first turn of an agent therefore runs that stack once on its own frame, so
+        the one-time cost sits at the start of the first episode and not in the first restart turn."""
         if not getattr(self, "_stack_primed", False):
             self._stack_primed = True
-            if images[0].is_cuda and self.num_history:
-                torch.stack([images[0]] * (self.num_history + 1))
-        return torch.stack(images)
+            if frame.is_cuda and self.num_history:
+                torch.stack([frame] * (self.num_history + 1))
 
     def _consume(self, out):
         self.output_ids = out.sequences
