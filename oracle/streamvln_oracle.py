@@ -39,6 +39,7 @@ compared with the SAME scheme instead of with bf16; parity of these modes is the
 from __future__ import annotations
 
 import math
+import threading
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -105,6 +106,9 @@ def qdq_e4m3_rows(x: torch.Tensor) -> torch.Tensor:
     return q * sc
 
 
+_DQ_LOCK = threading.Lock()
+
+
 class Fp8Emu:
     """The engine's two opt-in e4m3 modes as a CPU restatement (extension, no reference counterpart):
       decode  (svln_set_fp8_decode): the single-token decode step's four projections and EVERY lm_head product read per-row e4m3
@@ -135,7 +139,10 @@ class Fp8Emu:
         """dequantised e4m3 copy of w[name] (q/k/v rows are quantised row by row, so the engine's fused qkv matrix gives the same)"""
         t = self._dq.get(name)
         if t is None:
-            t = self._dq[name] = qdq_e4m3_rows(w[name])
+            with _DQ_LOCK:                      # (tests run several oracle episodes on threads over one shared cache of copies)
+                t = self._dq.get(name)
+                if t is None:
+                    t = self._dq[name] = qdq_e4m3_rows(w[name])
         return t
 
     def act(self, x: torch.Tensor) -> torch.Tensor:

@@ -856,8 +856,7 @@ def _oracle_env_logs(sc, n_envs, lengths, n_turns, env_steps=None):
     from streamvln_amd.synthetic import SyntheticPromptEncoder, synthetic_frame
     cfg = sc["cfg"]
     sd = util.synth_weights(cfg, SEED)
-    logs = []
-    for e in range(n_envs):
+    def solo(e):
         orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"])
         enc = SyntheticPromptEncoder(cfg, seed=7 + 31 * e, first_len=sc["lens"][0], memory_len=sc["lens"][1], later_len=sc["lens"][2])
         ag = StreamingAgent(orc, enc, num_frames=sc["num_frames"], num_future_steps=sc["nfs"], num_history=sc["num_history"],
@@ -865,7 +864,11 @@ def _oracle_env_logs(sc, n_envs, lengths, n_turns, env_steps=None):
         ag.decode_actions = lambda ids, ag=ag, e=e: [1] * lengths(e, len(ag.turn_log) - 1)
         while len(ag.turn_log) < n_turns[e]:
             ag.act(synthetic_frame(e, ag.step_id))
-        logs.append(ag.turn_log)
+        return ag.turn_log
+    # the envs are independent CPU jobs (the box has 128 host threads; torch releases the GIL inside its operators)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(n_envs, 8)) as ex:
+        logs = list(ex.map(solo, range(n_envs)))
     return logs
 
 

@@ -71,17 +71,26 @@ def _oracle_runs(cfg, sc, modes, seeds, workers=16):
     pre = lambda rgb: torch.from_numpy(O.siglip_preprocess(rgb))
     shared = {}
     out = {}
+    jobs = []
     for mode in modes:
         emu = None
         if mode != "plain":
             emu = O.Fp8Emu(decode=mode in ("decode", "both"), gemm=mode in ("gemm", "both"))
             emu._dq = shared
         for seed in (seeds[mode] if isinstance(seeds, dict) else seeds):
-            orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"], fp8=emu)
-            log = run_scenario(orc, dict(sc, prompt_seed=seed), preprocess=pre)
-            out[(mode, seed)] = [(r["out"].sequences[0].tolist(), r["out"].hidden.numpy().copy(), list(r["out"].margins), r["out"].cache_len)
-                                 for r in log]
-            del orc, log
+            jobs.append((mode, seed, emu))
+
+    def episode(job):
+        mode, seed, emu = job
+        orc = O.OracleStreamVLN(cfg, sd, num_history=sc["num_history"], fp8=emu)
+        log = run_scenario(orc, dict(sc, prompt_seed=seed), preprocess=pre)
+        return (mode, seed), [(r["out"].sequences[0].tolist(), r["out"].hidden.numpy().copy(), list(r["out"].margins), r["out"].cache_len)
+                              for r in log]
+    # the episodes are independent CPU jobs (the box has 128 host threads; torch releases the GIL inside its operators)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+        for key, val in ex.map(episode, jobs):
+            out[key] = val
     del shared
     gc.collect()
     return out
