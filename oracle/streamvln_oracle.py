@@ -490,4 +490,6 @@ class OracleStreamVLN:
             x = w["model.embed_tokens.weight"][tok][None]
             h = qwen2_forward(w, cfg, x, len(cache), cache, self.fp8, "decode")[-1]
         assert len(cache) == L_total + len(out) - 1
-        return GenerateOutput(torch.tensor([out], dtype=torch.long), cache, torch.stack(hid), margins)
+        go = GenerateOutput(torch.tensor([out], dtype=torch.long), cache, torch.stack(hid), margins)
+        go.own_picks = list(self.own_picks)                  # == the sequence unless teacher_tokens steered this turn
+        return go
