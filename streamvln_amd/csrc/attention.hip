@@ -68,7 +68,7 @@ template <int I, int N, typename F> SVLN_DEV void static_for(F&& f) {
 // KG > 1 (one-frame ViT): the workgroup is KG key groups of WAVES waves; group kg walks key tiles kg, kg + KG, ... of the SAME 32 * WAVES query
 // rows through its own K / Vt tile pair in LDS, so KG tiles are in flight per workgroup at once, and the groups' (m, l, O) are merged through
 // LDS at the end: the split-KV partials never leave the CU and there is no combine launch.
-template <typename T, int HD, int WAVES, int KG = 1, bool PF = true>
+template <typename T, int HD, int WAVES, int KG = 1, int PF = 1>
 __global__ __launch_bounds__(WAVES * 64 * KG, (KG == 1 && WAVES == 4 && sizeof(T) == 2) ? 2 : 1) void attn_kernel(AttnArgs p) {
     using G = AttnGeom<T, HD>;
     constexpr int NT = WAVES * 64;              // threads of one key group: they stage its tiles
@@ -128,105 +128,104 @@ __global__ __launch_bounds__(WAVES * 64 * KG, (KG == 1 && WAVES == 4 && sizeof(T
 
     // 4-wave workgroups (prefill / ViT): the next tile's K / Vt loads are issued into registers right after the barrier
     // that publishes the current tile and stay in flight under its MFMAs (one tile of HBM/L2 latency hidden per tile).
-    constexpr bool PREFETCH = WAVES == 4 || (KG > 1 && PF);
-    constexpr int KTOT_ = 64 * G::HDC, VTOT_ = G::VROWS * G::VC;
-    constexpr int KLP = (KTOT_ + NT - 1) / NT, VLP = (VTOT_ + NT - 1) / NT;
-    uint4 pk[PREFETCH ? KLP : 1], pv[PREFETCH ? VLP : 1];
-    auto load_regs = [&](int kt) {
+    // (PF: 0 = no register prefetch, 1 = K and Vt, 2 = K only -- the head_dim 128 key groups: both tiles would need 64 registers per lane)
+    constexpr bool PFK = WAVES == 4 || (KG > 1 && PF >= 1), PFV = WAVES == 4 || (KG > 1 && PF == 1);
+    constexpr int KTOT = 64 * G::HDC, VTOT = G::VROWS * G::VC, B = WAVES == 1 ? 4 : 8;
+    constexpr int KL = (KTOT + NT - 1) / NT, VL = (VTOT + NT - 1) / NT;
+    uint4 pk[PFK ? KL : 1], pv[PFV ? VL : 1];
+    auto tile_ptrs = [&](int kt, const char*& gk, const char*& gv) {
         const int pg = kt == kt0 ? page0 : (p.page_table ? p.page_table[kt] : kt);
-        const char* gk = (const char*)p.Kpool + (size_t)pg * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
-        const char* gv = (const char*)p.Vpool + (size_t)pg * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
-#pragma unroll
-        for (int u = 0; u < KLP; ++u) {
-            const int q = tid + u * NT;
-            pk[u] = q < KTOT_ ? *(const uint4*)(gk + (size_t)q * 16) : zero_chunk();
-        }
-#pragma unroll
-        for (int u = 0; u < VLP; ++u) {
-            const int q = tid + u * NT;
-            pv[u] = q < VTOT_ ? *(const uint4*)(gv + (size_t)q * 16) : zero_chunk();
+        gk = (const char*)p.Kpool + (size_t)pg * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
+        gv = (const char*)p.Vpool + (size_t)pg * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
+    };
+    auto put_k = [&](int q, const uint4& v) {
+        const int row = q / G::HDC, c = q - row * G::HDC;
+        *(uint4*)(sK + k_off<G>(row, c)) = v;
+    };
+    auto put_v = [&](int q, const uint4& v) {
+        const int row = q / G::VC, c = q - row * G::VC;
+        if (sizeof(T) == 4) {
+            *(uint4*)(sV + v_off_f32(row, c)) = v;
+        } else {
+            *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(v.x, v.y);
+            *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(v.z, v.w);
         }
     };
-    auto store_regs = [&]() {
+    auto load_regs = [&](int kt) {
+        const char *gk, *gv;
+        tile_ptrs(kt, gk, gv);
+        if (PFK) {
 #pragma unroll
-        for (int u = 0; u < KLP; ++u) {
-            const int q = tid + u * NT;
-            if (q < KTOT_) {
-                const int row = q / G::HDC, c = q - row * G::HDC;
-                *(uint4*)(sK + k_off<G>(row, c)) = pk[u];
+            for (int u = 0; u < KL; ++u) {
+                const int q = tid + u * NT;
+                pk[u] = q < KTOT ? *(const uint4*)(gk + (size_t)q * 16) : zero_chunk();
             }
         }
+        if (PFV) {
 #pragma unroll
-        for (int u = 0; u < VLP; ++u) {
-            const int q = tid + u * NT;
-            if (q < VTOT_) {
-                const int row = q / G::VC, c = q - row * G::VC;
-                if (sizeof(T) == 4) {
-                    *(uint4*)(sV + v_off_f32(row, c)) = pv[u];
-                } else {
-                    *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(pv[u].x, pv[u].y);
-                    *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(pv[u].z, pv[u].w);
-                }
+            for (int u = 0; u < VL; ++u) {
+                const int q = tid + u * NT;
+                pv[u] = q < VTOT ? *(const uint4*)(gv + (size_t)q * 16) : zero_chunk();
             }
         }
     };
-    if (PREFETCH && kt_begin < kt_end) load_regs(kt_begin);
+    if (PFK && kt_begin < kt_end) load_regs(kt_begin);
 
     for (int it = 0; it < n_iter; ++it) {
         const int kt = kt_begin + it * KG;
         const bool act = KG == 1 || kt < kt_end;        // (a key group past its last tile only keeps the barriers)
-        const int page = kt == kt0 ? page0 : (p.page_table ? p.page_table[kt] : kt);
-        const char* gK = (const char*)p.Kpool + (size_t)page * k_page_stride + (size_t)kh * 64 * G::HDP * sizeof(T);
-        const char* gV = (const char*)p.Vpool + (size_t)page * v_page_stride + (size_t)kh * G::VROWS * 64 * sizeof(T);
-        // ---- stage K and Vt tiles: coalesced 16-byte loads issued in batches (all in flight before the first
-        //      dependent LDS write), swizzled LDS writes
-        if (PREFETCH) {
-            if (act) store_regs();
-        } else {
-            constexpr int KTOT = 64 * G::HDC, VTOT = G::VROWS * G::VC, B = WAVES == 1 ? 4 : 8;
-            constexpr int KL = (KTOT + NT - 1) / NT, VL = (VTOT + NT - 1) / NT;
+        // ---- stage K and Vt tiles: from the prefetch registers, or coalesced 16-byte loads issued in batches (all in flight before the
+        //      first dependent LDS write); swizzled LDS writes
+        if (act) {
+            const char *gK, *gV;
+            if (!PFK || !PFV) tile_ptrs(kt, gK, gV);
+            if (PFK) {
 #pragma unroll
-            for (int b0 = 0; b0 < KL; b0 += B) {
-                uint4 t[B];
-#pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    const int q = tid + (b0 + u) * NT;
-                    t[u] = (b0 + u < KL && q < KTOT) ? *(const uint4*)(gK + (size_t)q * 16) : zero_chunk();
+                for (int u = 0; u < KL; ++u) {
+                    const int q = tid + u * NT;
+                    if (q < KTOT) put_k(q, pk[u]);
                 }
+            } else {
 #pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    const int q = tid + (b0 + u) * NT;
-                    if (b0 + u < KL && q < KTOT) {
-                        const int row = q / G::HDC, c = q - row * G::HDC;
-                        *(uint4*)(sK + k_off<G>(row, c)) = t[u];
+                for (int b0 = 0; b0 < KL; b0 += B) {
+                    uint4 t[B];
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        const int q = tid + (b0 + u) * NT;
+                        t[u] = (b0 + u < KL && q < KTOT) ? *(const uint4*)(gK + (size_t)q * 16) : zero_chunk();
+                    }
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        const int q = tid + (b0 + u) * NT;
+                        if (b0 + u < KL && q < KTOT) put_k(q, t[u]);
                     }
                 }
             }
+            if (PFV) {
 #pragma unroll
-            for (int b0 = 0; b0 < VL; b0 += B) {
-                uint4 t[B];
-#pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    const int q = tid + (b0 + u) * NT;
-                    t[u] = (b0 + u < VL && q < VTOT) ? *(const uint4*)(gV + (size_t)q * 16) : zero_chunk();
+                for (int u = 0; u < VL; ++u) {
+                    const int q = tid + u * NT;
+                    if (q < VTOT) put_v(q, pv[u]);
                 }
+            } else {
 #pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    const int q = tid + (b0 + u) * NT;
-                    if (b0 + u < VL && q < VTOT) {
-                        const int row = q / G::VC, c = q - row * G::VC;
-                        if (sizeof(T) == 4) {
-                            *(uint4*)(sV + v_off_f32(row, c)) = t[u];
-                        } else {
-                            *(uint2*)(sV + v_off_bf16(row, 2 * c)) = make_uint2(t[u].x, t[u].y);
-                            *(uint2*)(sV + v_off_bf16(row, 2 * c + 1)) = make_uint2(t[u].z, t[u].w);
-                        }
+                for (int b0 = 0; b0 < VL; b0 += B) {
+                    uint4 t[B];
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        const int q = tid + (b0 + u) * NT;
+                        t[u] = (b0 + u < VL && q < VTOT) ? *(const uint4*)(gV + (size_t)q * 16) : zero_chunk();
+                    }
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        const int q = tid + (b0 + u) * NT;
+                        if (b0 + u < VL && q < VTOT) put_v(q, t[u]);
                     }
                 }
             }
         }
         __syncthreads();
-        if (PREFETCH && kt + KG < kt_end) load_regs(kt + KG);
+        if (PFK && kt + KG < kt_end) load_regs(kt + KG);
         if (act) {
 
         // ---- S^T[j] = K_tile[j*32 .. j*32+31] . Q^T   (rows = keys, col = this lane's query)
@@ -340,10 +339,12 @@ __global__ __launch_bounds__(WAVES * 64 * KG, (KG == 1 && WAVES == 4 && sizeof(T
     l += __shfl_xor(l, 32, 64);
     if constexpr (KG > 1) {
         // ---- merge of the key groups (the loop ended on a barrier: the tiles are dead).  (m, l) of every group and row -> each lane scales its
-        // O by exp2(m - M) / L -> fp32 rows in LDS -> all threads sum the KG rows and store 4 channels each.
+        // O by exp2(m - M) -> fp32 rows in LDS -> all threads sum the KG rows, divide by L and store 4 channels each (or, under a grid-level
+        // key split on top, write the merged (O, M, L) partial row of this split for attn_combine_kernel).
         constexpr int ROWS = WAVES * 32, OP = HD + ATTN_PART_PAD;
         float* sML = (float*)smem;                                  // [KG][ROWS] x (m, l)
-        float* sO = (float*)(smem + KG * ROWS * 8);                 // [KG][ROWS][OP]
+        float* sFin = (float*)(smem + KG * ROWS * 8);               // [ROWS] x (M, L)
+        float* sO = (float*)(smem + (KG + 1) * ROWS * 8);           // [KG][ROWS][OP]
         const int rowl = wave * 32 + r;
         if (h == 0) *(float2*)(sML + (kg * ROWS + rowl) * 2) = make_float2(m, l);
         __syncthreads();
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(WAVES * 64 * KG, (KG == 1 && WAVES == 4 && sizeof(T
             const float2 ml = *(const float2*)(sML + (g * ROWS + rowl) * 2);
             L += ml.x == -INFINITY ? 0.0f : ml.y * fast_exp2(ml.x - M);
         }
-        const float f = (m == -INFINITY || !(L > 0.0f)) ? 0.0f : fast_exp2(m - M) / L;
+        if (kg == 0 && h == 0) *(float2*)(sFin + rowl * 2) = make_float2(M, L);
+        const float f = m == -INFINITY ? 0.0f : fast_exp2(m - M);
         float* od = sO + (size_t)(kg * ROWS + rowl) * OP;
 #pragma unroll
         for (int d = 0; d < G::DT; ++d)
@@ -376,10 +378,18 @@ __global__ __launch_bounds__(WAVES * 64 * KG, (KG == 1 && WAVES == 4 && sizeof(T
                 const float4 v = *(const float4*)(sO + (size_t)(g * ROWS + row) * OP + c4 * 4);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
+            const float2 fin = *(const float2*)(sFin + row * 2);
+            if (p.nsplit > 1) {
+                float* dst = p.part + (((size_t)blockIdx.z * p.n_kv_total + kh) * p.rows_pad + rho_o) * OP;
+                *(float4*)(dst + c4 * 4) = acc;
+                if (c4 == 0) { dst[HD] = fin.x; dst[HD + 1] = fin.y; }
+                continue;
+            }
+            const float inv = fin.y > 0.0f ? 1.0f / fin.y : 0.0f;
             const int qi_o = rho_o / p.G, qg_o = rho_o - qi_o * p.G;
             T* orow = (T*)p.O + (size_t)(frame * p.T + qi_o) * p.o_stride + (size_t)(head0 + qg_o) * HD + c4 * 4;
-            if (sizeof(T) == 2) *(uint2*)orow = make_uint2(pack_bf16x2(acc.x, acc.y), pack_bf16x2(acc.z, acc.w));
-            else *(float4*)orow = acc;
+            if (sizeof(T) == 2) *(uint2*)orow = make_uint2(pack_bf16x2(acc.x * inv, acc.y * inv), pack_bf16x2(acc.z * inv, acc.w * inv));
+            else *(float4*)orow = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         }
         return;
     }
@@ -649,19 +659,19 @@ template <typename T, int HD, int WAVES> void launch_attn_t(hipStream_t s, const
 // One ViT frame, bf16, measured (tools/kbench.py attn under rocprofv3): split-KV 3 + combine 15.6 + 7.4 us; 4 groups with the register
 // prefetch 14.3; 4 groups without it 19.3; 6 groups without 20.1; 6 groups with it 34.8 (12 waves leave 168 VGPRs: 72 spilled).
 // fp32 (the verification engine): 3 groups, no prefetch (its tiles are twice the bytes: LDS and registers).
-template <typename T> struct VitGroups { static constexpr int KG = sizeof(T) == 2 ? 4 : 3; static constexpr bool PF = sizeof(T) == 2; };
+template <typename T> struct VitGroups { static constexpr int KG = sizeof(T) == 2 ? 4 : 3; static constexpr int PF = sizeof(T) == 2 ? 1 : 0; };
 template <typename T, int HD, int KG_> struct GroupGeom {
     using G = AttnGeom<T, HD>;
     static constexpr int WAVES = 2, ROWS = WAVES * 32;
     static constexpr int KG = KG_;
     static constexpr size_t TILES = (size_t)KG * (G::K_TILE_BYTES + G::V_TILE_BYTES);
-    static constexpr size_t MERGE = (size_t)KG * ROWS * (8 + (HD + ATTN_PART_PAD) * 4);
+    static constexpr size_t MERGE = (size_t)(KG + 1) * ROWS * 8 + (size_t)KG * ROWS * (HD + ATTN_PART_PAD) * 4;
     static constexpr size_t LDS = TILES > MERGE ? TILES : MERGE;
 };
-template <typename T, int HD, int KG, bool PF> void launch_attn_groups(hipStream_t s, const AttnArgs& a) {
+template <typename T, int HD, int KG, int PF> void launch_attn_groups(hipStream_t s, const AttnArgs& a) {
     using GG = GroupGeom<T, HD, KG>;
     const int rows = a.T * a.G;
-    dim3 grid((rows + GG::ROWS - 1) / GG::ROWS, a.n_kv_total, 1), block(GG::WAVES * 64 * GG::KG);
+    dim3 grid((rows + GG::ROWS - 1) / GG::ROWS, a.n_kv_total, a.nsplit), block(GG::WAVES * 64 * GG::KG);
     hipLaunchKernelGGL((attn_kernel<T, HD, GG::WAVES, GG::KG, PF>), grid, block, GG::LDS, s, a);
 }
 
@@ -674,7 +684,8 @@ template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, in
         return;
     }
     if (a.key_groups > 1) {
-        if (a.nsplit != 1 || head_dim != 72 || a.key_groups != attn_key_groups<T>()) throw std::runtime_error("attention: key groups need head_dim 72, nsplit 1 and key_groups == attn_key_groups<T>()");
+        if (head_dim != 72 || a.key_groups != attn_key_groups<T>(head_dim))
+            throw std::runtime_error("attention: key groups are built for head_dim 72 with key_groups == attn_key_groups<T>(72)");
         launch_attn_groups<T, 72, VitGroups<T>::KG, VitGroups<T>::PF>(s, a);
         return;
     }
@@ -701,9 +712,9 @@ void attention_init_attrs() {
     set_max_lds((const void*)attn_kernel<bf16, 72, 2, VitGroups<bf16>::KG, VitGroups<bf16>::PF>, GroupGeom<bf16, 72, VitGroups<bf16>::KG>::LDS);
     set_max_lds((const void*)attn_kernel<float, 72, 2, VitGroups<float>::KG, VitGroups<float>::PF>, GroupGeom<float, 72, VitGroups<float>::KG>::LDS);
 }
-template <typename T> int attn_key_groups() { return VitGroups<T>::KG; }
-template int attn_key_groups<bf16>();
-template int attn_key_groups<float>();
+template <typename T> int attn_key_groups(int head_dim) { return head_dim == 72 ? VitGroups<T>::KG : 1; }
+template int attn_key_groups<bf16>(int);
+template int attn_key_groups<float>(int);
 template void launch_attention<bf16>(hipStream_t, const AttnArgs&, int, int);
 template void launch_attention<float>(hipStream_t, const AttnArgs&, int, int);
 template void launch_attention_combine<bf16>(hipStream_t, const AttnArgs&, int);

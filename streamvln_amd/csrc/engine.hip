@@ -490,7 +490,7 @@ public:
         const int wgs = ((S + 127) / 128) * F * vheads, rows_pad = ((S + 127) / 128) * 128;
         // (measured: 6 splits are slower than 3 -- the fp32 partials double -- and unsplit is 35 us against 18 + 8 for split + combine)
         // one frame, head_dim 72: the key split stays inside the workgroup (key groups merged through LDS): 14.3 us against 15.6 + 7.4
-        if (wgs < 192 && vtiles >= 6 && vhd == 72) { a.key_groups = attn_key_groups<T>(); return a; }
+        if (wgs < 192 && vtiles >= 6 && vhd == 72) { a.key_groups = attn_key_groups<T>(72); return a; }
         // (other head dims)
         if (wgs < 192 && vtiles >= 6 && (size_t)3 * F * vheads * rows_pad * (vhd + ATTN_PART_PAD) <= attn_part_elems) {
             a.nsplit = 3; a.tiles_per_split = (vtiles + 2) / 3; a.rows_pad = rows_pad;
@@ -840,6 +840,9 @@ public:
             a.causal = 1; a.dyn_kv_len = nullptr; a.nsplit = 1; a.tiles_per_split = pages_per_env;
             // few row blocks (steady turn: 12 x nkv workgroups): split the keys as well so the chip is filled
             const int rows = Tn * a.G, wgs = ((rows + 127) / 128) * nkv, tiles = (kv_len + PAGE - 1) / PAGE;
+            // (the ViT's in-workgroup key groups were tried here as well -- 96 workgroups of 4 groups x 2 waves under a 2-way grid split, K
+            //  prefetched in registers: steady prefill 9.00 against 9.01-9.03 ms per turn in two alternating rounds, +0.15-0.19 without the
+            //  grid split; not kept)
             if (rows <= PREFILL_SPLIT_ROWS && wgs < 128 && tiles >= 4) {
                 int ns = (256 + wgs - 1) / wgs;
                 if (ns > 8) ns = 8;

@@ -160,11 +160,11 @@ struct AttnArgs {
     size_t part_bstride;
     int batch;
     const int* skip;              // optional device flag: decode attention / combine are no-ops when *skip != 0
-    int key_groups;               // > 1: split-KV inside the workgroup (64 query rows x key groups, merged through LDS; head_dim 72, nsplit 1)
+    int key_groups;               // > 1: split-KV inside the workgroup (64 query rows x key groups, merged through LDS); nsplit > 1 on top: the merge writes the split's partial row
 };
 template <typename T> void launch_attention(hipStream_t s, const AttnArgs& a, int head_dim, int waves);
 template <typename T> void launch_attention_combine(hipStream_t s, const AttnArgs& a, int head_dim);
-template <typename T> int attn_key_groups();       // the key-group count launch_attention<T> is built for (AttnArgs::key_groups)
+template <typename T> int attn_key_groups(int head_dim);       // the key-group count launch_attention<T> is built for at this head dim (AttnArgs::key_groups)
 
 // Persistent batch-1 decode layer (decode_layer.hip): merge of this layer's split-KV attention partials, o_proj + residual,
 // post_attention_layernorm, gate/up + SwiGLU, down_proj + residual, and the NEXT layer's input_layernorm + q|k|v projection, as ONE launch
