@@ -204,7 +204,8 @@ int svln_feature_cache_stats(svln_engine* h, int64_t* hits, int64_t* misses);
 /* force_cfg (op tests and A/B runs only; the engine always passes 0): low 12 bits = tile configuration, 0 = heuristic, 128 = 128x128,
  * 129 = 128x128 with two in-workgroup K groups, 256 = 256x256 (bf16: 8-phase schedule), 258 = 256x256 with two K slices, 264 = 256x64
  * (M <= 256), 64 = 64x64, 32 = 32x128 (M <= 32); flag bits: 0x1000 row tiles fastest in the workgroup order, 0x10000 column tiles
- * fastest, 0x4000 stage-ring kernel for the 256x256 tile, 0x8000 32x32x16 form of the 8-phase schedule.
+ * fastest, 0x4000 stage-ring kernel for the 256x256 tile, 0x8000 32x32x16 form of the 8-phase schedule, 0x20000 direct 2-byte stores in the 8-phase
+ * epilogue instead of the LDS-staged 16-byte row chunks.
  * force_split: 0 = heuristic, S >= 1 = 256x128 tiles (256x64 with force_cfg 264) with S K-splits */
 int svln_op_gemm(svln_engine* h, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* res,
                  int ldr, int res_mod, int M, int N, int K, int epi, int force_cfg, int force_split);

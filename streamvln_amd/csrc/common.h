@@ -107,15 +107,19 @@ SVLN_DEV float wave_max(float v) {
     return v;
 }
 
-// activation functions (fp32)
+// activation functions (fp32).  sigmoid on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each: a few ulp of fp32 in all, far
+// inside the 1e-3 parity bar) instead of libm's expf / tanhf and an IEEE division: an epilogue evaluates 64-128 activations per lane per
+// 256 x 256 tile, and with libm (~35-50 instructions each) that was 35 of the 90 us of the nine-frame fc1 product and ~10 % of gate/up at
+// T = 1952.  gelu_tanh uses 0.5 (1 + tanh u) = sigmoid(2u).
+SVLN_DEV float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 SVLN_DEV float gelu_tanh_f(float x) {      // ACT2FN["gelu_pytorch_tanh"]  (siglip_encoder.py:83)
-    const float k = 0.7978845608028654f;   // sqrt(2/pi)
-    return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+    const float k2 = 2.0f * 0.7978845608028654f;   // 2 sqrt(2/pi)
+    return x * sigmoid_f(k2 * (x + 0.044715f * x * x * x));
 }
 SVLN_DEV float gelu_erf_f(float x) {       // nn.GELU()  (multimodal_projector/builder.py:45)
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }
-SVLN_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
+SVLN_DEV float silu_f(float x) { return x * sigmoid_f(x); }
 
 // ---- synthetic weights: identical arithmetic to streamvln_amd/weights.py ---------------------
 SVLN_DEV uint64_t splitmix64(uint64_t z) {

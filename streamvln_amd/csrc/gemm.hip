@@ -297,6 +297,76 @@ SVLN_DEV void p8_epilogue16(const GemmArgs& p, int row0, int col0, int wave, int
 }
 
 
+// The same epilogue with the stores staged through LDS (bf16 outputs, 16-byte aligned rows).  In the 16x16 accumulator layout a lane holds ONE
+// column of 4 rows, so the direct form above stores 2 bytes per lane in 32-byte pieces: measured on isolated launches, 115 of the 542 us of the
+// T = 1952 gate/up product and 35 of the 90 us of the nine-frame fc1 were those stores.  Here each wave rounds its values into a private LDS
+// tile (64 rows at a time, rows padded by 16 B: the four row groups of a store instruction fall into different banks), reads it back as
+// 16-byte row chunks and stores whole 64- / 128-byte row segments.  Same arithmetic and rounding as p8_epilogue16: bit-identical outputs.
+// The caller has put a workgroup barrier between the last stage reads and this call (the tiles overlay the stage ring).
+template <typename T, int EPI>
+SVLN_DEV void p8_epilogue16_staged(const GemmArgs& p, char* smem, int row0, int col0, int wave, int lane, const f32x4 (&acc)[8][4]) {
+    static_assert(sizeof(T) == 2, "staged epilogue: 2-byte outputs");
+    constexpr bool GLU = EPI == EPI_SWIGLU;
+    constexpr int COLS = GLU ? 32 : 64, STRIDE = COLS * 2 + 16, CPR = COLS / 8;       // chunks of 8 outputs per row
+    const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, g = lane >> 4;
+    char* sE = smem + wave * (64 * STRIDE);
+    T* Cc = (T*)p.C;
+    const T* bias = (const T*)p.bias;
+    const T* res = (const T*)p.res;
+    const int ncols_out = GLU ? p.N / 2 : p.N;                                          // columns of C
+    const int cbase = GLU ? ((col0 + wc * 64) >> 1) : col0 + wc * 64;                   // first C column of this wave
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mq = 0; mq < 4; ++mq) {
+            const int mi = half * 4 + mq;
+            if constexpr (GLU) {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *(T*)(sE + (mq * 16 + 4 * g + e) * STRIDE + (nj * 16 + r16) * 2) = from_f32<T>(silu_f(acc[mi][nj][e]) * acc[mi][nj + 2][e]);
+            } else {
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const int nn = col0 + wc * 64 + nj * 16 + r16;
+                    const float bv = (bias && nn < p.N) ? to_f32(bias[nn]) : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = epi_act<T, EPI>(acc[mi][nj][e] + bv);
+                        if (res) {
+                            const int m = row0 + wr * 128 + mi * 16 + 4 * g + e;
+                            if (m < p.M && nn < p.N) {
+                                const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+                                v += to_f32(res[(size_t)rr * p.ldr + nn]);
+                            }
+                        }
+                        *(T*)(sE + (mq * 16 + 4 * g + e) * STRIDE + (nj * 16 + r16) * 2) = from_f32<T>(v);
+                    }
+                }
+            }
+        }
+        // (the wave's own LDS writes and reads are ordered; no other wave touches this tile)
+#pragma unroll
+        for (int k = 0; k < 64 * CPR / 64; ++k) {
+            const int q = k * 64 + lane, row = q / CPR, c = q - row * CPR;
+            const uint4 v = *(const uint4*)(sE + row * STRIDE + c * 16);
+            const int m = row0 + wr * 128 + half * 64 + row, cc = cbase + c * 8;
+            if (m >= p.M || cc >= ncols_out) continue;
+            T* dst = Cc + (size_t)m * p.ldc + cc;
+            if (cc + 8 <= ncols_out) {
+                *(uint4*)dst = v;
+            } else {            // ragged last chunk of a row: element by element (unrolled: no address of v is taken)
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (cc + t < ncols_out) ((uint16_t*)dst)[t] = (uint16_t)((t & 1) ? w4[t >> 1] >> 16 : w4[t >> 1] & 0xFFFFu);
+            }
+        }
+    }
+}
+
+
 // Same tiles and epilogues, operands staged with LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR or
 // ds_write hop).  One wave instruction fills 1 KiB of LDS = 8 consecutive 128-byte tile rows, lane l -> row l/8,
 // physical chunk l%8; the XOR swizzle is applied on the per-lane SOURCE address (the LDS image must stay lane-linear).
@@ -523,7 +593,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
                         }
                 }
             } else {
-                p8_epilogue16<T, EPI>(p, row0, col0, wave_all, lane, acc16);
+                // 2-byte outputs with 16-byte aligned rows (every product of the engine): stores staged through LDS; otherwise the direct form
+                bool staged = false;
+                if constexpr (sizeof(T) == 2 && EPI != EPI_ARGMAX)
+                    staged = (p.ldc & 7) == 0 && ((size_t)p.C & 15) == 0 && ((EPI == EPI_SWIGLU ? col0 >> 1 : col0) & 7) == 0 && !(p.force_cfg & 0x20000);
+                if (staged) {
+                    if constexpr (sizeof(T) == 2 && EPI != EPI_ARGMAX) {
+                        __syncthreads();            // every wave is done with the stage ring: the epilogue tiles overlay it
+                        p8_epilogue16_staged<T, EPI>(p, smem, row0, col0, wave_all, lane, acc16);
+                    }
+                } else {
+                    p8_epilogue16<T, EPI>(p, row0, col0, wave_all, lane, acc16);
+                }
             }
             return;
         }

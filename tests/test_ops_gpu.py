@@ -125,6 +125,7 @@ def test_gemm_fused_norm(dtype, M, N, K, split, kind, expect_fused):
     (1000, 640, 128, _lib.EPI_NONE),           # two K tiles: prologue only
     (1952, 2048, 1024, _lib.EPI_SWIGLU),       # gate/up epilogue
     (6561, 3456, 1152, _lib.EPI_NONE),         # nine-frame ViT qkv: 26 x 14 tiles, the last column tile half empty, 18 K tiles
+    (1000, 4304, 1152, _lib.EPI_GELU_TANH),    # fc1-shaped: GELU epilogue, the last column tile 208 wide
 ])
 def test_gemm_8phase_equals_stage_ring(M, N, K, epi):
     """The 8-phase schedule of the 256x256 tile (gemm.hip: p8_mainloop).  Its 32x32x16 form (force_cfg 256 | 0x8000) accumulates every output
@@ -163,6 +164,47 @@ def test_gemm_8phase_equals_stage_ring(M, N, K, epi):
         assert torch.equal(out.view(torch.int16), ring.view(torch.int16)), ("32x32x16 form", rep, int((out.view(torch.int16) != ring.view(torch.int16)).sum()))
         out = run(256, 3.0)
         assert torch.equal(out.view(torch.int16), first16.view(torch.int16)), ("16x16x32 form", rep, int((out.view(torch.int16) != first16.view(torch.int16)).sum()))
+    # the LDS-staged stores of the 16x16x32 form (16-byte aligned output rows) against its direct 2-byte stores (| 0x20000): the same bits
+    direct = run(256 | 0x20000, 7.0)
+    assert torch.equal(direct.view(torch.int16), first16.view(torch.int16)), ("staged vs direct epilogue", int((direct.view(torch.int16) != first16.view(torch.int16)).sum()))
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU_TANH, _lib.EPI_SWIGLU])
+def test_gemm_8phase_staged_epilogue_ragged_rows_and_residual(epi):
+    """p8_epilogue16_staged: output rows wider than N (ldc > N), N not a multiple of 8 (the last 16-byte chunk of a row is stored element
+    by element and the padding columns keep their fill), M not a multiple of 64, bias and a residual with res_mod -- bit for bit against the
+    direct epilogue."""
+    m = engine(TINY, torch.bfloat16)
+    M, K = 700, 192
+    N = 1100 if epi != _lib.EPI_SWIGLU else 1088          # SwiGLU: whole [gate 32 | up 32] blocks
+    n_out = N // 2 if epi == _lib.EPI_SWIGLU else N
+    ldc = (n_out + 15) // 8 * 8                            # 16-byte aligned rows, a few padding columns
+    A = q(rnd((M, K), 81), torch.bfloat16).to(torch.bfloat16).cuda()
+    W = q(rnd((N, K), 82, 1.0 / math.sqrt(K)), torch.bfloat16).to(torch.bfloat16).cuda()
+    b = q(rnd((N,), 83, 0.1), torch.bfloat16).to(torch.bfloat16).cuda()
+    R = q(rnd((100, n_out), 84), torch.bfloat16).to(torch.bfloat16).cuda()
+    glu = epi == _lib.EPI_SWIGLU
+
+    def run(cfg):
+        out = torch.full((M, ldc), 9.0, dtype=torch.bfloat16, device="cuda")
+        torch.cuda.synchronize()
+        chk(m._lib.svln_op_gemm(m._h, ptr(A), K, ptr(W), K, ptr(out), ldc, None if glu else ptr(b), None if glu else ptr(R), n_out, 0 if glu else 100,
+                                M, N, K, epi, cfg, 0))
+        torch.cuda.synchronize()
+        return out
+    staged, direct = run(256), run(256 | 0x20000)
+    assert torch.equal(staged.view(torch.int16), direct.view(torch.int16)), int((staged.view(torch.int16) != direct.view(torch.int16)).sum())
+    assert bool((staged[:, n_out:] == 9.0).all())
+    acc = A.float().cpu() @ W.float().cpu().t()
+    if glu:
+        acc = acc.view(M, N // 64, 2, 32)
+        exp = (O.silu(acc[:, :, 0]) * acc[:, :, 1]).reshape(M, n_out)
+    else:
+        exp = acc + b.float().cpu()
+        if epi == _lib.EPI_GELU_TANH:
+            exp = O.gelu_tanh(exp)
+        exp = exp + R.float().cpu()[torch.arange(M) % 100]
+    assert_close(staged[:, :n_out], exp, torch.bfloat16, f"staged epilogue epi {epi}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
