@@ -875,6 +875,37 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 //   Y[m] = (C[m] - mean) * rsqrt(var + eps) * g + b   when norm_b != 0   (LayerNorm: SigLIP ln2 / next layer's ln1)
 // N <= 4096, N % 4 == 0; blockDim = the row's quads rounded up to whole waves.  Same arithmetic as
 // splitk_epilogue_kernel<EPI_NONE> followed by rmsnorm_kernel / layernorm_kernel on the rounded row.
+// four consecutive elements as one 8- / 16-byte access when the address allows it (the rows of this kernel start at multiples of 4 columns)
+template <typename T> SVLN_DEV void load4(const T* ptr, bool vec, float (&out)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 w = *(const uint2*)ptr;
+            out[0] = __uint_as_float(w.x << 16); out[1] = __uint_as_float(w.x & 0xFFFF0000u);
+            out[2] = __uint_as_float(w.y << 16); out[3] = __uint_as_float(w.y & 0xFFFF0000u);
+        } else {
+            const float4 w = *(const float4*)ptr;
+            out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = to_f32(ptr[e]);
+    }
+}
+template <typename T> SVLN_DEV void store4(T* ptr, bool vec, const T (&v)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 2) {
+            const uint16_t* h = (const uint16_t*)v;
+            *(uint2*)ptr = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        } else {
+            *(float4*)ptr = make_float4(to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3]));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ptr[e] = v[e];
+    }
+}
+template <typename T> SVLN_DEV bool vec4_ok(const void* base, size_t ld) { return ((size_t)base % (4 * sizeof(T))) == 0 && ld % 4 == 0; }
+
 template <typename T>
 __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
     __shared__ float red[2][16];
@@ -898,15 +929,19 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
             const float4 t = *(const float4*)(src + s * slab);
             a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
         }
+        float bf[4] = {0, 0, 0, 0}, rf[4] = {0, 0, 0, 0};
+        if (bias) load4<T>(bias + n0, vec4_ok<T>(bias, 0), bf);
+        if (res) load4<T>(res + (size_t)rr * p.ldr + n0, vec4_ok<T>(res, p.ldr), rf);
+        T t4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = a[e] + (bias ? to_f32(bias[n0 + e]) : 0.0f);
-            if (res) x += to_f32(res[(size_t)rr * p.ldr + n0 + e]);
-            const T t = from_f32<T>(x);
-            Cc[(size_t)m * p.ldc + n0 + e] = t;
-            v[e] = to_f32(t);
+            float x = a[e] + bf[e];
+            if (res) x += rf[e];
+            t4[e] = from_f32<T>(x);
+            v[e] = to_f32(t4[e]);
             s1 = nb ? s1 + v[e] : fmaf(v[e], v[e], s1);
         }
+        store4<T>(Cc + (size_t)m * p.ldc + n0, vec4_ok<T>(Cc, p.ldc), t4);
     }
     auto block_sum = [&](float x, int k) {
         x = wave_sum(x);
@@ -926,19 +961,27 @@ __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
         }
         const float sc = rsqrtf(block_sum(s2, 1) / (float)p.N + p.norm_eps);
         if (live) {
+            float gf[4], nf[4];
+            load4<T>(g + n0, vec4_ok<T>(g, 0), gf);
+            load4<T>(nb + n0, vec4_ok<T>(nb, 0), nf);
+            T y4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Y[(size_t)m * p.N + n0 + e] = from_f32<T>((v[e] - mu) * sc * to_f32(g[n0 + e]) + to_f32(nb[n0 + e]));
+            for (int e = 0; e < 4; ++e) y4[e] = from_f32<T>((v[e] - mu) * sc * gf[e] + nf[e]);
+            store4<T>(Y + (size_t)m * p.N + n0, vec4_ok<T>(Y, p.N), y4);
         }
     } else {
         const float sc = rsqrtf(t1 / (float)p.N + p.norm_eps);
         float yq[4] = {0, 0, 0, 0};
         if (live) {
+            float gf[4];
+            load4<T>(g + n0, vec4_ok<T>(g, 0), gf);
+            T y4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const T y = from_f32<T>(to_f32(g[n0 + e]) * (v[e] * sc));
-                Y[(size_t)m * p.N + n0 + e] = y;
-                yq[e] = to_f32(y);
+                y4[e] = from_f32<T>(gf[e] * (v[e] * sc));
+                yq[e] = to_f32(y4[e]);
             }
+            store4<T>(Y + (size_t)m * p.N + n0, vec4_ok<T>(Y, p.N), y4);
         }
         if constexpr (sizeof(T) == 2) {
             if (p.norm_q8) {              // e4m3 copy of the row (quant_fp8_rows_kernel's arithmetic on the rounded values)
