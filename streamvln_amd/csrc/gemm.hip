@@ -812,6 +812,37 @@ __global__ __launch_bounds__(C::THREADS) void gemm_glds_kernel(GemmArgs p) {
     }
 }
 
+// four consecutive elements as one 8- / 16-byte access when the address allows it (the rows of this kernel start at multiples of 4 columns)
+template <typename T> SVLN_DEV void load4(const T* ptr, bool vec, float (&out)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 w = *(const uint2*)ptr;
+            out[0] = __uint_as_float(w.x << 16); out[1] = __uint_as_float(w.x & 0xFFFF0000u);
+            out[2] = __uint_as_float(w.y << 16); out[3] = __uint_as_float(w.y & 0xFFFF0000u);
+        } else {
+            const float4 w = *(const float4*)ptr;
+            out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = to_f32(ptr[e]);
+    }
+}
+template <typename T> SVLN_DEV void store4(T* ptr, bool vec, const T (&v)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 2) {
+            const uint16_t* h = (const uint16_t*)v;
+            *(uint2*)ptr = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        } else {
+            *(float4*)ptr = make_float4(to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3]));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ptr[e] = v[e];
+    }
+}
+template <typename T> SVLN_DEV bool vec4_ok(const void* base, size_t ld) { return ((size_t)base % (4 * sizeof(T))) == 0 && ld % 4 == 0; }
+
 // sum split-K slabs + epilogue.  One thread = 4 consecutive output columns of one row.
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
@@ -824,8 +855,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
     T* Cc = (T*)p.C;
     const T* bias = (const T*)p.bias;
     const T* res = (const T*)p.res;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / quads), n0 = n_out_begin + (int)(idx % quads) * 4;
+    const bool cvec = vec4_ok<T>(Cc, p.ldc);
+    // (M * quads < 2^31 for every product of the engine: 32-bit index arithmetic; the launcher asserts it)
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * 256u) {
+        const int m = (int)(idx / (unsigned)quads), n0 = n_out_begin + (int)(idx - (unsigned)m * (unsigned)quads) * 4;
         float out[4];
         if (EPI == EPI_SWIGLU) {
             // output j lives in packed columns (j/32)*64 + j%32 (gate) and +32 (up); 4 consecutive j share a block
@@ -863,9 +896,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
                 out[e] = v;
             }
         }
+        if (n0 + 3 < n_out_total) {
+            const T o4[4] = {from_f32<T>(out[0]), from_f32<T>(out[1]), from_f32<T>(out[2]), from_f32<T>(out[3])};
+            store4<T>(Cc + (size_t)m * p.ldc + n0, cvec, o4);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n0 + e < n_out_total) Cc[(size_t)m * p.ldc + n0 + e] = from_f32<T>(out[e]);
+            for (int e = 0; e < 4; ++e)
+                if (n0 + e < n_out_total) Cc[(size_t)m * p.ldc + n0 + e] = from_f32<T>(out[e]);
+        }
     }
 }
 
@@ -875,37 +913,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 //   Y[m] = (C[m] - mean) * rsqrt(var + eps) * g + b   when norm_b != 0   (LayerNorm: SigLIP ln2 / next layer's ln1)
 // N <= 4096, N % 4 == 0; blockDim = the row's quads rounded up to whole waves.  Same arithmetic as
 // splitk_epilogue_kernel<EPI_NONE> followed by rmsnorm_kernel / layernorm_kernel on the rounded row.
-// four consecutive elements as one 8- / 16-byte access when the address allows it (the rows of this kernel start at multiples of 4 columns)
-template <typename T> SVLN_DEV void load4(const T* ptr, bool vec, float (&out)[4]) {
-    if (vec) {
-        if constexpr (sizeof(T) == 2) {
-            const uint2 w = *(const uint2*)ptr;
-            out[0] = __uint_as_float(w.x << 16); out[1] = __uint_as_float(w.x & 0xFFFF0000u);
-            out[2] = __uint_as_float(w.y << 16); out[3] = __uint_as_float(w.y & 0xFFFF0000u);
-        } else {
-            const float4 w = *(const float4*)ptr;
-            out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = to_f32(ptr[e]);
-    }
-}
-template <typename T> SVLN_DEV void store4(T* ptr, bool vec, const T (&v)[4]) {
-    if (vec) {
-        if constexpr (sizeof(T) == 2) {
-            const uint16_t* h = (const uint16_t*)v;
-            *(uint2*)ptr = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-        } else {
-            *(float4*)ptr = make_float4(to_f32(v[0]), to_f32(v[1]), to_f32(v[2]), to_f32(v[3]));
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ptr[e] = v[e];
-    }
-}
-template <typename T> SVLN_DEV bool vec4_ok(const void* base, size_t ld) { return ((size_t)base % (4 * sizeof(T))) == 0 && ld % 4 == 0; }
-
 template <typename T>
 __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(GemmArgs p) {
     __shared__ float red[2][16];
@@ -1177,6 +1184,7 @@ template <typename T, int EPI> bool launch_reduce(hipStream_t s, const GemmArgs&
     const size_t work = (size_t)a.M * ((n_out - n_begin) / 4 + 1);
     int grid = (int)((work + 255) / 256);
     if (grid > 4096) grid = 4096;
+    if (work >= ((size_t)1 << 31)) throw std::runtime_error("split-K reduce: more than 2^31 output quads");      // (the kernel indexes in 32 bits)
     hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, a);
     return false;
 }
