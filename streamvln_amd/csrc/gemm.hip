@@ -1240,6 +1240,8 @@ template <typename T, int EPI> bool launch_epi(hipStream_t s, GemmArgs a) {
         //  the re-staging of their 8 MB activation panel: prefill +0.03 .. +0.4 ms per turn in the in-turn A/B, so they stay on 128x128 split-K)
         const int ktiles = (a.K / EPC + 7) / 8;
         const bool can_split = a.ws != nullptr && a.N % 4 == 0 && !(EPI == EPI_SWIGLU && a.N % 64 != 0) && (size_t)2 * a.M * a.N <= a.ws_elems;
+        // (o_proj at T = 1952 -- K = 3584, 56 K tiles -- on the same two slices: restart turn 47.3 / 46.6 and 47.4 / 47.1 ms against 48.2 / 47.2 and
+        //  47.6 / 47.1 on 128x128 tiles + a separate RMSNorm in two alternating rounds: inside the noise, not taken)
         if (((tilesbig >= 96 && tilesbig <= 128 && a.M > 512 && ktiles >= 128 && a.force_split == 0 && (a.force_cfg & 0xFFF) == 0) || (a.force_cfg & 0xFFF) == 258) &&
             a.zeros && !a.a_scale && can_split) {
             a.nsplit = 2;
